@@ -1,0 +1,683 @@
+/*
+ * hsw_oracle.c -- CPU restatement of the halo2-dynamic-sha256 witness path.
+ * TEST INFRASTRUCTURE ONLY (see hsw_oracle.h for scope, assumptions, pinning).
+ *
+ * Every function cites the reference lines it follows; statement order inside
+ * each function is the reference's, because the order of gate calls *is* the
+ * order of the gate-cell stream.
+ */
+#include "hsw_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ field */
+/* BN254 scalar field modulus (halo2curves::bn256::Fr), little-endian limbs. */
+static const ofe_t FR_P = {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL,
+                            0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+
+static inline ofe_t fe_u64(uint64_t v) { ofe_t r = {{v, 0, 0, 0}}; return r; }
+static inline int fe_is_u64(const ofe_t *a) { return (a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const ofe_t *a, const ofe_t *b) {
+    return a->l[0] == b->l[0] && a->l[1] == b->l[1] && a->l[2] == b->l[2] && a->l[3] == b->l[3];
+}
+static inline int fe_is_zero(const ofe_t *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_geq(const ofe_t *a, const ofe_t *b) {
+    for (int i = 3; i >= 0; i--) {
+        if (a->l[i] > b->l[i]) return 1;
+        if (a->l[i] < b->l[i]) return 0;
+    }
+    return 1;
+}
+static inline ofe_t fe_sub_raw(const ofe_t *a, const ofe_t *b) {
+    ofe_t r; u128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - borrow;
+        r.l[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+    return r;
+}
+static ofe_t fe_add(const ofe_t *a, const ofe_t *b) {
+    ofe_t r; u128 carry = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 s = (u128)a->l[i] + b->l[i] + carry;
+        r.l[i] = (uint64_t)s;
+        carry = s >> 64;
+    }
+    /* both inputs < p < 2^254, so no carry out of 256 bits */
+    if (fe_geq(&r, &FR_P)) r = fe_sub_raw(&r, &FR_P);
+    return r;
+}
+static ofe_t fe_neg(const ofe_t *a) {
+    if (fe_is_zero(a)) return *a;
+    return fe_sub_raw(&FR_P, a);
+}
+/* 512-bit by p reduction, bit-serial.  Only reached if an operand of a gate
+ * multiplication does not fit 64 bits, which the gadget never does; kept so
+ * the oracle is a field-arithmetic restatement, not a u64 one. */
+static ofe_t fe_mul_slow(const ofe_t *a, const ofe_t *b) {
+    uint64_t prod[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        u128 carry = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 t = (u128)a->l[i] * b->l[j] + prod[i + j] + carry;
+            prod[i + j] = (uint64_t)t;
+            carry = t >> 64;
+        }
+        prod[i + 4] = (uint64_t)carry;
+    }
+    ofe_t r = {{0, 0, 0, 0}};
+    for (int bit = 511; bit >= 0; bit--) {
+        /* r = 2r + bit  (mod p); r < p < 2^254 so 2r+1 < 2^256 */
+        uint64_t top = 0;
+        for (int i = 0; i < 4; i++) {
+            uint64_t nt = r.l[i] >> 63;
+            r.l[i] = (r.l[i] << 1) | top;
+            top = nt;
+        }
+        r.l[0] |= (prod[bit / 64] >> (bit % 64)) & 1;
+        if (fe_geq(&r, &FR_P)) r = fe_sub_raw(&r, &FR_P);
+    }
+    return r;
+}
+static ofe_t fe_mul(const ofe_t *a, const ofe_t *b) {
+    if (fe_is_u64(a) && fe_is_u64(b)) {
+        u128 t = (u128)a->l[0] * b->l[0];      /* < 2^128 < p: already reduced */
+        ofe_t r = {{(uint64_t)t, (uint64_t)(t >> 64), 0, 0}};
+        return r;
+    }
+    return fe_mul_slow(a, b);
+}
+/* halo2-base ScalarField::get_lower_32 / get_lower_64: low bits of the
+ * canonical representation (call sites compression.rs:224,228,274,278,814,818). */
+static inline uint32_t fe_lower_32(const ofe_t *a) { return (uint32_t)a->l[0]; }
+static inline uint64_t fe_lower_64(const ofe_t *a) { return a->l[0]; }
+
+/* ---------------------------------------------------------------- context */
+struct oracle_ctx {
+    int num_bits_lookup;          /* spread.rs:24 */
+    int num_advice_columns;       /* spread.rs:25 */
+    uint64_t num_limb_sum;        /* spread.rs:26 */
+    uint64_t row_offset;          /* spread.rs:27 */
+    int check;
+    ofe_t *gate; size_t gate_cap, gate_len;
+    ofe_t *dense, *spread; size_t col_stride; uint64_t row_base;
+    oracle_stats_t st;
+    int failed; char msg[256];
+};
+
+static void ofail(oracle_ctx *c, const char *what, uint64_t a, uint64_t b) {
+    if (!c->failed) {
+        c->failed = 1;
+        snprintf(c->msg, sizeof c->msg, "%s (0x%llx vs 0x%llx) at gate cell %zu", what,
+                 (unsigned long long)a, (unsigned long long)b, c->gate_len);
+    }
+}
+
+oracle_ctx *oracle_create(int num_bits_lookup, int num_advice_columns, int check) {
+    /* spread.rs:37  debug_assert_eq!(16 % num_bits_lookup, 0) */
+    if (num_bits_lookup <= 0 || num_bits_lookup > 16 || 16 % num_bits_lookup != 0) return NULL;
+    if (num_advice_columns <= 0) return NULL;
+    oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->num_bits_lookup = num_bits_lookup;
+    c->num_advice_columns = num_advice_columns;
+    c->check = check;
+    return c;
+}
+void oracle_destroy(oracle_ctx *c) { free(c); }
+void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap, ofe_t *dense,
+                        ofe_t *spread, size_t col_stride, uint64_t row_base) {
+    c->gate = gate; c->gate_cap = gate_cap; c->gate_len = 0;
+    c->dense = dense; c->spread = spread; c->col_stride = col_stride; c->row_base = row_base;
+}
+void oracle_set_cursor(oracle_ctx *c, uint64_t n) {
+    c->num_limb_sum = n;
+    c->row_offset = n / (uint64_t)c->num_advice_columns;   /* spread.rs:228-231 closed form */
+}
+uint64_t oracle_get_cursor(const oracle_ctx *c) { return c->num_limb_sum; }
+size_t oracle_gate_len(const oracle_ctx *c) { return c->gate_len; }
+void oracle_get_stats(const oracle_ctx *c, oracle_stats_t *out) { *out = c->st; }
+int oracle_failed(const oracle_ctx *c, const char **msg) {
+    if (msg) *msg = c->msg;
+    return c->failed;
+}
+
+/* ------------------------------------------------- halo2-base gate mirror */
+/* One advice cell of the gate stream. */
+static inline void cell(oracle_ctx *c, const ofe_t *v) {
+    if (c->gate) {
+        if (c->gate_len < c->gate_cap) c->gate[c->gate_len] = *v;
+        else ofail(c, "gate buffer overflow", c->gate_len, c->gate_cap);
+    }
+    c->gate_len++;
+    c->st.gate_cells++;
+}
+/* GateInstructions::load_witness -> [v] */
+static ofe_t g_load_witness(oracle_ctx *c, ofe_t v) {
+    c->st.load_witness++;
+    cell(c, &v);
+    return v;
+}
+/* GateInstructions::load_zero: cached in the Context (assumption A2). */
+static ofe_t g_load_zero(oracle_ctx *c) { c->st.load_zero++; return fe_u64(0); }
+/* GateInstructions::add -> [a, b, 1, a+b] */
+static ofe_t g_add(oracle_ctx *c, ofe_t a, ofe_t b) {
+    c->st.add++;
+    ofe_t one = fe_u64(1), out = fe_add(&a, &b);
+    cell(c, &a); cell(c, &b); cell(c, &one); cell(c, &out);
+    return out;
+}
+/* GateInstructions::neg -> [a, -a, 1, 0] */
+static ofe_t g_neg(oracle_ctx *c, ofe_t a) {
+    c->st.neg++;
+    ofe_t one = fe_u64(1), zero = fe_u64(0), out = fe_neg(&a);
+    cell(c, &a); cell(c, &out); cell(c, &one); cell(c, &zero);
+    return out;
+}
+/* GateInstructions::mul_add(a, b, c) = a*b + c -> [c, a, b, out] */
+static ofe_t g_mul_add(oracle_ctx *c, ofe_t a, ofe_t b, ofe_t cc) {
+    c->st.mul_add++;
+    ofe_t ab = fe_mul(&a, &b), out = fe_add(&ab, &cc);
+    cell(c, &cc); cell(c, &a); cell(c, &b); cell(c, &out);
+    return out;
+}
+/* GateInstructions::assert_equal: copy constraint only. */
+static void g_assert_equal(oracle_ctx *c, ofe_t a, ofe_t b) {
+    c->st.assert_equal++;
+    if (c->check && !fe_eq(&a, &b)) ofail(c, "assert_equal violated", a.l[0], b.l[0]);
+}
+/* RangeInstructions::range_check(a, bits): constraint a < 2^bits. */
+static void r_range_check(oracle_ctx *c, ofe_t a, int bits) {
+    if (bits == 16) c->st.range_check16++;
+    else if (bits == 32) c->st.range_check32++;
+    else c->st.range_check_other++;
+    if (c->check) {
+        if (!fe_is_u64(&a) || (bits < 64 && (a.l[0] >> bits) != 0))
+            ofail(c, "range_check violated", a.l[0], (uint64_t)bits);
+    }
+}
+
+/* -------------------------------------------------------------- utils.rs */
+/* utils.rs:6-14 fe_to_bits_le(val, size): little-endian bits of the canonical
+ * value, whole bytes, zero-extended to `size`; the reference underflows
+ * (panics) if the byte-rounded bit length exceeds `size`. */
+static int fe_to_bits_le(oracle_ctx *c, const ofe_t *v, int size, uint8_t *bits) {
+    int nbytes = 32;
+    while (nbytes > 1 && ((v->l[(nbytes - 1) / 8] >> (8 * ((nbytes - 1) % 8))) & 0xff) == 0) nbytes--;
+    /* BigUint::to_bytes_le() of zero is [0] -> 8 bits */
+    int nbits = nbytes * 8;
+    if (nbits > size) { ofail(c, "fe_to_bits_le: value wider than size (reference panics)", v->l[0], (uint64_t)size); nbits = size; }
+    for (int i = 0; i < nbits; i++) bits[i] = (uint8_t)((v->l[i / 64] >> (i % 64)) & 1);
+    for (int i = nbits; i < size; i++) bits[i] = 0;
+    return size;
+}
+/* utils.rs:16-29 bits_le_to_fe (callers pass <= 64 bits). */
+static ofe_t bits_le_to_fe(const uint8_t *bits, int n) {
+    ofe_t r = {{0, 0, 0, 0}};
+    for (int i = 0; i < n; i++) if (bits[i]) r.l[i / 64] |= 1ULL << (i % 64);
+    return r;
+}
+
+/* ------------------------------------------------------------- spread.rs */
+/* spread.rs:211-218: interleave zeros -- bit i of val goes to bit 2i. */
+static ofe_t spread_value_of(oracle_ctx *c, const ofe_t *val) {
+    uint8_t vb[32], sb[64];
+    fe_to_bits_le(c, val, 32, vb);
+    memset(sb, 0, sizeof sb);
+    for (int i = 0; i < 32; i++) sb[2 * i] = vb[i];
+    return bits_le_to_fe(sb, 64);
+}
+uint64_t oracle_spread_table_entry(uint32_t i) {
+    uint64_t s = 0;
+    for (int b = 0; b < 32; b++) s |= (uint64_t)((i >> b) & 1) << (2 * b);
+    return s;
+}
+
+/* spread.rs:196-233 spread_limb: two raw region.assign_advice cells at
+ * (denses[col], row_offset) / (spreads[col], row_offset), one load_witness. */
+static ofe_t sc_spread_limb(oracle_ctx *c, ofe_t limb) {
+    c->st.spread_limb_calls++;
+    uint64_t column_idx = c->num_limb_sum % (uint64_t)c->num_advice_columns;    /* :202 */
+    ofe_t spread_value = spread_value_of(c, &limb);                              /* :211-218 */
+    if (c->check) {
+        /* the "spread lookup" (spread.rs:56-62): (dense, spread) must be a table row */
+        if (!fe_is_u64(&limb) || limb.l[0] >= (1ULL << c->num_bits_lookup))
+            ofail(c, "spread lookup: dense limb outside table", limb.l[0], 1ULL << c->num_bits_lookup);
+        else if (spread_value.l[0] != oracle_spread_table_entry((uint32_t)limb.l[0]))
+            ofail(c, "spread lookup: spread mismatch", spread_value.l[0], limb.l[0]);
+    }
+    if (c->dense && c->spread) {
+        if (c->row_offset < c->row_base || c->row_offset - c->row_base >= c->col_stride)
+            ofail(c, "chip row outside buffer", c->row_offset, c->row_base);
+        else {
+            size_t at = (size_t)column_idx * c->col_stride + (size_t)(c->row_offset - c->row_base);
+            c->dense[at] = limb;                                                 /* :203-208 */
+            c->spread[at] = spread_value;                                        /* :219-224 */
+        }
+    }
+    c->st.chip_cells += 2;
+    ofe_t assigned_spread_value = g_load_witness(c, spread_value);               /* :225 */
+    c->num_limb_sum += 1;                                                        /* :228 */
+    if (column_idx == (uint64_t)c->num_advice_columns - 1) c->row_offset += 1;   /* :229-231 */
+    return assigned_spread_value;
+}
+
+/* spread.rs:76-123 SpreadConfig::spread */
+static ofe_t sc_spread(oracle_ctx *c, ofe_t dense) {
+    c->st.spread_calls++;
+    int limb_bits = c->num_bits_lookup;                 /* :83 */
+    int num_limbs = 16 / limb_bits;                     /* :84 */
+    ofe_t assigned_limbs[16];
+    /* :85 decompose(v, num_limbs, limb_bits): little-endian limb_bits-wide digits */
+    for (int idx = 0; idx < num_limbs; idx++) {
+        uint64_t limb = (dense.l[0] >> (limb_bits * idx)) & ((1ULL << limb_bits) - 1);
+        assigned_limbs[idx] = g_load_witness(c, fe_u64(limb));          /* :86-88 */
+    }
+    {
+        ofe_t limbs_sum = g_load_zero(c);                               /* :90 */
+        for (int idx = 0; idx < num_limbs; idx++)                       /* :91-98 */
+            limbs_sum = g_mul_add(c, assigned_limbs[idx], fe_u64(1ULL << (limb_bits * idx)), limbs_sum);
+        g_assert_equal(c, limbs_sum, dense);                            /* :104-108 */
+    }
+    ofe_t assigned_spread = g_load_zero(c);                             /* :110 */
+    for (int idx = 0; idx < num_limbs; idx++) {                         /* :112-121 */
+        ofe_t spread_limb = sc_spread_limb(c, assigned_limbs[idx]);
+        assigned_spread = g_mul_add(c, spread_limb, fe_u64(1ULL << (2 * limb_bits * idx)), assigned_spread);
+    }
+    return assigned_spread;
+}
+
+/* spread.rs:139-163 decompose_even_and_odd_unchecked */
+static void sc_decompose_even_and_odd_unchecked(oracle_ctx *c, ofe_t spread, ofe_t *even, ofe_t *odd) {
+    c->st.even_odd_calls++;
+    uint8_t bits[32], eb[16], ob[16];
+    fe_to_bits_le(c, &spread, 32, bits);                /* :145 */
+    for (int i = 0; i < 16; i++) { eb[i] = bits[2 * i]; ob[i] = bits[2 * i + 1]; }   /* :146-153 */
+    ofe_t even_val = bits_le_to_fe(eb, 16), odd_val = bits_le_to_fe(ob, 16);         /* :154-157 */
+    *even = g_load_witness(c, even_val);                /* :158 */
+    *odd = g_load_witness(c, odd_val);                  /* :159 */
+    r_range_check(c, *even, 16);                        /* :160 */
+    r_range_check(c, *odd, 16);                         /* :161 */
+}
+
+/* -------------------------------------------------------- compression.rs */
+static const uint32_t ROUND_CONSTANTS[64] = {           /* FIPS 180-4 K; compression.rs:992-1001 */
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static const uint32_t INIT_STATE[8] = {                 /* compression.rs:1003-1012 */
+    0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+typedef struct { ofe_t lo, hi; } spread_u32;            /* compression.rs:17 SpreadU32 */
+
+/* compression.rs:215-246 */
+static spread_u32 state_to_spread_u32(oracle_ctx *c, ofe_t x) {
+    ofe_t lo = fe_u64(fe_lower_32(&x) & ((1u << 16) - 1));      /* :222-225 */
+    ofe_t hi = fe_u64(fe_lower_32(&x) >> 16);                   /* :226-229 */
+    ofe_t assigned_lo = g_load_witness(c, lo);                  /* :230 */
+    ofe_t assigned_hi = g_load_witness(c, hi);                  /* :231 */
+    ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 16), assigned_lo);   /* :232-237 */
+    g_assert_equal(c, x, composed);                             /* :238-242 */
+    spread_u32 r;
+    r.lo = sc_spread(c, assigned_lo);                           /* :243 */
+    r.hi = sc_spread(c, assigned_hi);                           /* :244 */
+    return r;
+}
+
+/* compression.rs:266-295 */
+static ofe_t mod_u32(oracle_ctx *c, ofe_t x) {
+    ofe_t lo = fe_u64(fe_lower_32(&x));                                     /* :272-275 */
+    ofe_t hi = fe_u64((fe_lower_64(&x) >> 32) & ((1ULL << 32) - 1));        /* :276-279 */
+    ofe_t assigned_lo = g_load_witness(c, lo);                              /* :280 */
+    ofe_t assigned_hi = g_load_witness(c, hi);                              /* :281 */
+    r_range_check(c, assigned_lo, 32);                                      /* :282 */
+    ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 32), assigned_lo);   /* :283-288 */
+    g_assert_equal(c, x, composed);                                         /* :289-293 */
+    return assigned_lo;
+}
+
+/* compression.rs:521-530 */
+static ofe_t three_add(oracle_ctx *c, ofe_t x, ofe_t y, ofe_t z) {
+    ofe_t add1 = g_add(c, x, y);
+    return g_add(c, add1, z);
+}
+
+/* the { spread(even); spread(odd); 2*odd+even == whole } block that ch, maj
+ * and sigma_generic each repeat (compression.rs:344-354 and siblings) */
+static void recheck_even_odd(oracle_ctx *c, ofe_t even, ofe_t odd, ofe_t whole) {
+    ofe_t even_spread = sc_spread(c, even);
+    ofe_t odd_spread = sc_spread(c, odd);
+    ofe_t sum = g_mul_add(c, fe_u64(2), odd_spread, even_spread);
+    g_assert_equal(c, sum, whole);
+}
+
+/* compression.rs:297-405 */
+static ofe_t ch(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
+    ofe_t p_lo = g_add(c, x.lo, y.lo);                          /* :309-313 */
+    ofe_t p_hi = g_add(c, x.hi, y.hi);                          /* :314-318 */
+    const uint64_t MASK_EVEN_32 = 0x55555555;                   /* :319 */
+    ofe_t x_neg_lo = g_neg(c, x.lo);                            /* :320 */
+    ofe_t x_neg_hi = g_neg(c, x.hi);                            /* :321 */
+    ofe_t q_lo = three_add(c, fe_u64(MASK_EVEN_32), x_neg_lo, z.lo);    /* :322-328 */
+    ofe_t q_hi = three_add(c, fe_u64(MASK_EVEN_32), x_neg_hi, z.hi);    /* :329-335 */
+    ofe_t p_lo_even, p_lo_odd, p_hi_even, p_hi_odd, q_lo_even, q_lo_odd, q_hi_even, q_hi_odd;
+    sc_decompose_even_and_odd_unchecked(c, p_lo, &p_lo_even, &p_lo_odd);    /* :336-337 */
+    sc_decompose_even_and_odd_unchecked(c, p_hi, &p_hi_even, &p_hi_odd);    /* :338-339 */
+    sc_decompose_even_and_odd_unchecked(c, q_lo, &q_lo_even, &q_lo_odd);    /* :340-341 */
+    sc_decompose_even_and_odd_unchecked(c, q_hi, &q_hi_even, &q_hi_odd);    /* :342-343 */
+    recheck_even_odd(c, p_lo_even, p_lo_odd, p_lo);             /* :344-354 */
+    recheck_even_odd(c, p_hi_even, p_hi_odd, p_hi);             /* :355-365 */
+    recheck_even_odd(c, q_lo_even, q_lo_odd, q_lo);             /* :366-376 */
+    recheck_even_odd(c, q_hi_even, q_hi_odd, q_hi);             /* :377-387 */
+    ofe_t out_lo = g_add(c, p_lo_odd, q_lo_odd);                /* :388-392 */
+    ofe_t out_hi = g_add(c, p_hi_odd, q_hi_odd);                /* :393-397 */
+    return g_mul_add(c, out_hi, fe_u64(1ULL << 16), out_lo);    /* :398-403 */
+}
+
+/* compression.rs:460-519 */
+static ofe_t maj(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
+    ofe_t m_lo = three_add(c, x.lo, y.lo, z.lo);                /* :472-478 */
+    ofe_t m_hi = three_add(c, x.hi, y.hi, z.hi);                /* :479-485 */
+    ofe_t m_lo_even, m_lo_odd, m_hi_even, m_hi_odd;
+    sc_decompose_even_and_odd_unchecked(c, m_lo, &m_lo_even, &m_lo_odd);    /* :486-487 */
+    sc_decompose_even_and_odd_unchecked(c, m_hi, &m_hi_even, &m_hi_odd);    /* :488-489 */
+    recheck_even_odd(c, m_lo_even, m_lo_odd, m_lo);             /* :490-500 */
+    recheck_even_odd(c, m_hi_even, m_hi_odd, m_hi);             /* :501-511 */
+    return g_mul_add(c, m_hi_odd, fe_u64(1ULL << 16), m_lo_odd);        /* :512-517 */
+}
+
+/* compression.rs:702-882 */
+typedef struct { int starts[4], ends[4]; uint64_t coeffs[4]; } sigma_params;
+static ofe_t sigma_generic(oracle_ctx *c, const spread_u32 *x_spread, const sigma_params *sp) {
+    const int *starts = sp->starts, *ends = sp->ends;
+    const uint64_t *coeffs = sp->coeffs;
+    uint8_t bits[64];
+    fe_to_bits_le(c, &x_spread->lo, 32, bits);                  /* :715 */
+    fe_to_bits_le(c, &x_spread->hi, 32, bits + 32);             /* :716 */
+    ofe_t assigned[4];
+    for (int i = 0; i < 4; i++) {                               /* :719-734 assign_bits x4 */
+        uint8_t piece[64];
+        int n = 2 * ends[i] - 2 * starts[i];
+        memcpy(piece, bits + 2 * starts[i], (size_t)n);         /* :722 */
+        memset(piece + n, 0, (size_t)(64 - n));                 /* :723 */
+        assigned[i] = g_load_witness(c, bits_le_to_fe(piece, 64));      /* :724-726 */
+    }
+    {
+        ofe_t sum = assigned[0];                                /* :736 */
+        sum = g_mul_add(c, assigned[1], fe_u64(1ULL << (2 * starts[1])), sum);     /* :737-742 */
+        sum = g_mul_add(c, assigned[2], fe_u64(1ULL << (2 * starts[2])), sum);     /* :743-748 */
+        sum = g_mul_add(c, assigned[3], fe_u64(1ULL << (2 * starts[3])), sum);     /* :749-754 */
+        ofe_t x_composed = g_mul_add(c, x_spread->hi, fe_u64(1ULL << 32), x_spread->lo);   /* :755-760 */
+        g_assert_equal(c, x_composed, sum);                     /* :761-765 */
+    }
+    ofe_t r_spread;
+    {
+        ofe_t sum = g_load_zero(c);                             /* :780 */
+        for (int i = 0; i < 4; i++)                             /* :785-808 */
+            sum = g_mul_add(c, fe_u64(coeffs[i]), assigned[i], sum);
+        r_spread = sum;
+    }
+    ofe_t r_lo, r_hi;
+    {
+        ofe_t lo = fe_u64(fe_lower_32(&r_spread));                              /* :812-815 */
+        ofe_t hi = fe_u64((fe_lower_64(&r_spread) >> 32) & ((1ULL << 32) - 1)); /* :816-819 */
+        ofe_t assigned_lo = g_load_witness(c, lo);              /* :820 */
+        ofe_t assigned_hi = g_load_witness(c, hi);              /* :821 */
+        r_range_check(c, assigned_lo, 32);                      /* :822 */
+        r_range_check(c, assigned_hi, 32);                      /* :823 */
+        ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 32), assigned_lo);   /* :824-829 */
+        g_assert_equal(c, r_spread, composed);                  /* :830-834 */
+        r_lo = assigned_lo; r_hi = assigned_hi;
+    }
+    ofe_t r_lo_even, r_lo_odd, r_hi_even, r_hi_odd;
+    sc_decompose_even_and_odd_unchecked(c, r_lo, &r_lo_even, &r_lo_odd);    /* :843-844 */
+    sc_decompose_even_and_odd_unchecked(c, r_hi, &r_hi_even, &r_hi_odd);    /* :845-846 */
+    recheck_even_odd(c, r_lo_even, r_lo_odd, r_lo);             /* :852-862 */
+    recheck_even_odd(c, r_hi_even, r_hi_odd, r_hi);             /* :863-873 */
+    return g_mul_add(c, r_hi_even, fe_u64(1ULL << 16), r_lo_even);      /* :874-879 */
+}
+
+#define P2(n) (1ULL << (n))
+/* compression.rs:594-619 */
+static ofe_t sigma_upper0(oracle_ctx *c, const spread_u32 *x) {
+    static const sigma_params SP = {{0, 2, 13, 22}, {2, 13, 22, 32},
+                                    {P2(60) + P2(38) + P2(20), P2(0) + P2(42) + P2(24),
+                                       P2(22) + P2(0) + P2(46), P2(40) + P2(18) + P2(0)}};
+    return sigma_generic(c, x, &SP);
+}
+/* compression.rs:621-646 */
+static ofe_t sigma_upper1(oracle_ctx *c, const spread_u32 *x) {
+    static const sigma_params SP = {{0, 6, 11, 25}, {6, 11, 25, 32},
+                                    {P2(52) + P2(42) + P2(14), P2(0) + P2(54) + P2(26),
+                                       P2(10) + P2(0) + P2(36), P2(38) + P2(28) + P2(0)}};
+    return sigma_generic(c, x, &SP);
+}
+/* compression.rs:648-673 */
+static ofe_t sigma_lower0(oracle_ctx *c, const spread_u32 *x) {
+    static const sigma_params SP = {{0, 3, 7, 18}, {3, 7, 18, 32},
+                                    {P2(50) + P2(28), P2(0) + P2(56) + P2(34),
+                                       P2(8) + P2(0) + P2(42), P2(30) + P2(22) + P2(0)}};
+    return sigma_generic(c, x, &SP);
+}
+/* compression.rs:675-700 */
+static ofe_t sigma_lower1(oracle_ctx *c, const spread_u32 *x) {
+    static const sigma_params SP = {{0, 10, 17, 19}, {10, 17, 19, 32},
+                                    {P2(30) + P2(26), P2(0) + P2(50) + P2(46),
+                                       P2(14) + P2(0) + P2(60), P2(18) + P2(4) + P2(0)}};
+    return sigma_generic(c, x, &SP);
+}
+
+/* compression.rs:19-213 */
+int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
+                              const uint32_t pre_state[8], uint32_t next_state[8]) {
+    /* the caller's assigned_input_bytes / pre_state_words (lib.rs:162-173) */
+    ofe_t assigned_input_bytes[64], pre_state_words[8];
+    for (int i = 0; i < 64; i++) assigned_input_bytes[i] = fe_u64(block[i]);
+    for (int i = 0; i < 8; i++) pre_state_words[i] = fe_u64(pre_state[i]);
+
+    /* message schedule: :31-47 */
+    ofe_t message_u32s[64];
+    for (int w = 0; w < 16; w++) {
+        const ofe_t *bytes = &assigned_input_bytes[4 * w];
+        ofe_t sum = g_load_zero(c);                                         /* :34 */
+        for (int idx = 0; idx < 4; idx++)                                   /* :35-42 */
+            sum = g_mul_add(c, bytes[3 - idx], fe_u64(1ULL << (8 * idx)), sum);
+        message_u32s[w] = sum;
+    }
+    spread_u32 message_spreads[64];
+    for (int w = 0; w < 16; w++)                                            /* :53-56 */
+        message_spreads[w] = state_to_spread_u32(c, message_u32s[w]);
+    for (int idx = 16; idx < 64; idx++) {                                   /* :57-96 */
+        ofe_t term1 = sigma_lower1(c, &message_spreads[idx - 2]);           /* :60 */
+        ofe_t term3 = sigma_lower0(c, &message_spreads[idx - 15]);          /* :61 */
+        ofe_t sum = g_add(c, term1, message_u32s[idx - 7]);                 /* :65-69 */
+        sum = g_add(c, sum, term3);                                         /* :70-74 */
+        sum = g_add(c, sum, message_u32s[idx - 16]);                        /* :75-79 */
+        ofe_t new_w = mod_u32(c, sum);                                      /* :80 */
+        message_u32s[idx] = new_w;                                          /* :89 */
+        message_spreads[idx] = state_to_spread_u32(c, new_w);               /* :90-91 */
+    }
+
+    /* compression: :99-124 */
+    ofe_t a = pre_state_words[0], b = pre_state_words[1], cc = pre_state_words[2],
+          d = pre_state_words[3], e = pre_state_words[4], f = pre_state_words[5],
+          g = pre_state_words[6], h = pre_state_words[7];
+    spread_u32 a_spread = state_to_spread_u32(c, a);        /* :109 */
+    spread_u32 b_spread = state_to_spread_u32(c, b);        /* :110 */
+    spread_u32 c_spread = state_to_spread_u32(c, cc);       /* :111 */
+    spread_u32 e_spread = state_to_spread_u32(c, e);        /* :113 */
+    spread_u32 f_spread = state_to_spread_u32(c, f);        /* :114 */
+    spread_u32 g_spread = state_to_spread_u32(c, g);        /* :115 */
+    g_load_zero(c);                                         /* :123 */
+    g_load_zero(c);                                         /* :124 */
+    for (int idx = 0; idx < 64; idx++) {                    /* :125-196 */
+        ofe_t t1, t2;
+        {
+            ofe_t sigma_term = sigma_upper1(c, &e_spread);                  /* :130 */
+            ofe_t ch_term = ch(c, e_spread, f_spread, g_spread);            /* :131 */
+            ofe_t add1 = g_add(c, h, sigma_term);                           /* :138-142 */
+            ofe_t add2 = g_add(c, add1, ch_term);                           /* :143-147 */
+            ofe_t add3 = g_add(c, add2, fe_u64(ROUND_CONSTANTS[idx]));      /* :148-152 */
+            ofe_t add4 = g_add(c, add3, message_u32s[idx]);                 /* :153-157 */
+            t1 = mod_u32(c, add4);                                          /* :158 */
+        }
+        {
+            ofe_t sigma_term = sigma_upper0(c, &a_spread);                  /* :164 */
+            ofe_t maj_term = maj(c, a_spread, b_spread, c_spread);          /* :165 */
+            ofe_t add = g_add(c, sigma_term, maj_term);                     /* :166-170 */
+            t2 = mod_u32(c, add);                                           /* :171 */
+        }
+        h = g;                                              /* :174 */
+        g = f; g_spread = f_spread;                         /* :176-177 */
+        f = e; f_spread = e_spread;                         /* :178-179 */
+        {
+            ofe_t add = g_add(c, d, t1);                    /* :181 */
+            e = mod_u32(c, add);                            /* :182 */
+        }
+        e_spread = state_to_spread_u32(c, e);               /* :184 */
+        d = cc;                                             /* :185 */
+        cc = b; c_spread = b_spread;                        /* :187-188 */
+        b = a; b_spread = a_spread;                         /* :189-190 */
+        {
+            ofe_t add = g_add(c, t1, t2);                   /* :192 */
+            a = mod_u32(c, add);                            /* :193 */
+        }
+        a_spread = state_to_spread_u32(c, a);               /* :195 */
+    }
+    ofe_t new_states[8] = {a, b, cc, d, e, f, g, h};        /* :197 */
+    for (int i = 0; i < 8; i++) {                           /* :198-211 */
+        ofe_t add = g_add(c, new_states[i], pre_state_words[i]);
+        ofe_t out = mod_u32(c, add);
+        if (next_state) next_state[i] = fe_lower_32(&out);
+    }
+    return c->failed;
+}
+
+int oracle_witness_blocks(oracle_ctx *c, const uint8_t *blocks, const uint32_t *pre_states,
+                          size_t n, uint32_t *next_states) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t ns[8];
+        oracle_sha256_compression(c, blocks + 64 * i, pre_states + 8 * i, ns);
+        if (next_states) memcpy(next_states + 8 * i, ns, sizeof ns);
+    }
+    return c->failed;
+}
+
+/* ------------------------------------------------ plain SHA-256 (sha2 crate) */
+static inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+void oracle_plain_compress(uint32_t state[8], const uint8_t block[64]) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)block[4 * i] << 24) | ((uint32_t)block[4 * i + 1] << 16) |
+               ((uint32_t)block[4 * i + 2] << 8) | block[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = state[0], b = state[1], c = state[2], d = state[3], e = state[4], f = state[5],
+             g = state[6], h = state[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        uint32_t chv = (e & f) ^ (~e & g);
+        uint32_t t1 = h + S1 + chv + ROUND_CONSTANTS[i] + w[i];
+        uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    state[0] += a; state[1] += b; state[2] += c; state[3] += d;
+    state[4] += e; state[5] += f; state[6] += g; state[7] += h;
+}
+
+/* ------------------------------------------------------------------ lib.rs */
+/* lib.rs:71-349, value-level.  The digest epilogue's own cells (length
+ * constraints :122-151, is_equal/select :294-310, output bytes :311-341) are
+ * not emitted -- they are the out-of-scope front-end; the
+ * *selection rule* is followed so the digest is the reference's. */
+int oracle_digest(oracle_ctx *c, const uint8_t *input, size_t input_byte_size,
+                  size_t precomputed_input_len, size_t max_variable_byte_size,
+                  uint8_t digest[32], uint8_t *blocks_out, uint32_t *pre_states_out,
+                  uint32_t *next_states_out) {
+    const size_t one_round_size = 64;                                       /* :48 */
+    if (max_variable_byte_size % one_round_size != 0) return 10;           /* :57-59 */
+    size_t input_byte_size_with_9 = input_byte_size + 9;                    /* :78 */
+    size_t num_round = (input_byte_size_with_9 % one_round_size == 0)       /* :80-84 */
+                           ? input_byte_size_with_9 / one_round_size
+                           : input_byte_size_with_9 / one_round_size + 1;
+    size_t padded_size = one_round_size * num_round;                        /* :85 */
+    size_t max_variable_round = max_variable_byte_size / one_round_size;    /* :87 */
+    if (precomputed_input_len % one_round_size != 0) return 11;             /* :89 */
+    if (precomputed_input_len > padded_size ||
+        padded_size - precomputed_input_len > max_variable_byte_size) return 12;   /* :90 */
+    size_t zero_padding_byte_size = padded_size - input_byte_size_with_9;   /* :91 */
+    size_t remaining_byte_size = max_variable_byte_size + precomputed_input_len - padded_size;  /* :92 */
+    size_t precomputed_round = precomputed_input_len / one_round_size;      /* :93 */
+    if (remaining_byte_size != one_round_size * (max_variable_round + precomputed_round - num_round))
+        return 13;                                                          /* :94-97 */
+    size_t total = max_variable_byte_size + precomputed_input_len;
+    uint8_t *padded_inputs = (uint8_t *)calloc(total ? total : 1, 1);
+    if (!padded_inputs) return 14;
+    size_t n = 0;
+    memcpy(padded_inputs, input, input_byte_size); n += input_byte_size;   /* :98 */
+    padded_inputs[n++] = 0x80;                                              /* :99 */
+    n += zero_padding_byte_size;                                            /* :100-102 */
+    uint64_t bitlen = 8ULL * (uint64_t)input_byte_size;                     /* :103-108 */
+    for (int i = 7; i >= 0; i--) padded_inputs[n++] = (uint8_t)(bitlen >> (8 * i));
+    if (n != num_round * one_round_size) { free(padded_inputs); return 15; }   /* :110 */
+    n += remaining_byte_size;                                               /* :111-113 (zeros) */
+    if (n != total) { free(padded_inputs); return 16; }                     /* :114-117 */
+
+    uint32_t last_state[8];                                                 /* :155-160 */
+    memcpy(last_state, INIT_STATE, sizeof last_state);
+    for (size_t r = 0; r < precomputed_round; r++)
+        oracle_plain_compress(last_state, padded_inputs + r * one_round_size);
+
+    /* :180-238: always max_variable_round compressions */
+    size_t target_round = num_round - precomputed_round;                    /* :147-151 */
+    uint32_t output_h_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};                    /* :294-295 */
+    if (target_round == 0) memcpy(output_h_out, last_state, sizeof last_state);     /* n_round 0 candidate */
+    for (size_t r = 0; r < max_variable_round; r++) {
+        const uint8_t *blk = padded_inputs + precomputed_input_len + r * one_round_size;
+        uint32_t next[8];
+        if (blocks_out) memcpy(blocks_out + r * 64, blk, 64);
+        if (pre_states_out) memcpy(pre_states_out + r * 8, last_state, sizeof last_state);
+        oracle_sha256_compression(c, blk, last_state, next);                /* :183-189 */
+        if (next_states_out) memcpy(next_states_out + r * 8, next, sizeof next);
+        memcpy(last_state, next, sizeof next);                              /* :236 */
+        if (r + 1 == target_round) memcpy(output_h_out, next, sizeof next); /* :296-310 */
+    }
+    for (int i = 0; i < 8; i++) {                                           /* :311-341 be bytes */
+        digest[4 * i] = (uint8_t)(output_h_out[i] >> 24);
+        digest[4 * i + 1] = (uint8_t)(output_h_out[i] >> 16);
+        digest[4 * i + 2] = (uint8_t)(output_h_out[i] >> 8);
+        digest[4 * i + 3] = (uint8_t)output_h_out[i];
+    }
+    free(padded_inputs);
+    return c->failed ? 1 : 0;
+}
+
+int oracle_measure_shape(int num_bits_lookup, int num_advice_columns,
+                         uint64_t *gate_cells_per_block, uint64_t *limb_calls_per_block) {
+    oracle_ctx *c = oracle_create(num_bits_lookup, num_advice_columns, 1);
+    if (!c) return 1;
+    uint8_t blk[64];
+    for (int i = 0; i < 64; i++) blk[i] = (uint8_t)(i * 37 + 11);
+    uint32_t next[8];
+    oracle_sha256_compression(c, blk, INIT_STATE, next);
+    if (gate_cells_per_block) *gate_cells_per_block = c->gate_len;
+    if (limb_calls_per_block) *limb_calls_per_block = c->num_limb_sum;
+    int failed = c->failed;
+    oracle_destroy(c);
+    return failed;
+}

@@ -1,0 +1,131 @@
+/*
+ * hsw_oracle.h -- CPU restatement of the halo2-dynamic-sha256 witness path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the reported CPU
+ * baseline.  The product path (include/hsw.h -> libhsw.so, HIP) never links,
+ * loads or calls anything here.
+ *
+ * What it restates (all citations are paths under the reference tree):
+ *   src/compression.rs:19-213   sha256_compression  (call sequence)
+ *   src/compression.rs:215-246  state_to_spread_u32
+ *   src/compression.rs:266-295  mod_u32
+ *   src/compression.rs:297-405  ch
+ *   src/compression.rs:460-519  maj
+ *   src/compression.rs:521-530  three_add
+ *   src/compression.rs:594-882  sigma_upper0/1, sigma_lower0/1, sigma_generic
+ *   src/compression.rs:990-1012 ROUND_CONSTANTS, INIT_STATE
+ *   src/spread.rs:76-123        SpreadConfig::spread
+ *   src/spread.rs:139-163       decompose_even_and_odd_unchecked
+ *   src/spread.rs:196-233       spread_limb   (chip column / row placement)
+ *   src/utils.rs:6-29           fe_to_bits_le / bits_le_to_fe
+ *   src/lib.rs:71-349           Sha256DynamicConfig::digest (padding, prefix
+ *                               pre-hash, block loop, output selection)
+ *
+ * Arithmetic that lives in third-party code absent from the reference tree
+ * (halo2-base / halo2-ecc, git github.com/zkmove/halo2-lib rev 40ba7e3;
+ * sha2 0.10.6 compress256) is restated from its published semantics:
+ *   - field = BN254 scalar field Fr, canonical little-endian 4x64-bit limbs;
+ *   - FlexGate vertical gate q*(a + b*c - d) = 0 over 4 consecutive cells,
+ *     cell orders (ASSUMPTION A1, halo2-lib v0.2.x):
+ *         load_witness(v)  -> [v]
+ *         add(a,b)         -> [a, b, 1, a+b]
+ *         neg(a)           -> [a, -a, 1, 0]
+ *         mul_add(a,b,c)   -> [c, a, b, a*b+c]
+ *   - load_zero is cached by the Context and costs no stream cell
+ *     (ASSUMPTION A2); assert_equal / range_check add constraints only and
+ *     their halo2-base-internal cells are outside the stream.
+ *
+ * PINNING.  The reference holds no cell-level golden vectors and cannot be
+ * built here (no Rust toolchain, un-vendored git deps).  The oracle is pinned
+ * by (i) every digest-level known-answer vector of the reference's own tests
+ * (src/lib.rs:497-611), (ii) FIPS 180-4 / hashlib on random inputs, and
+ * (iii) self-checking every constraint the gadget emits (3,850 assert_equal,
+ * every range_check bound, every spread-table lookup per block) -- each
+ * witness cell is forced to a unique value by those constraints, so a
+ * restatement that satisfies all of them in source order is value-exact.
+ * Cell PLACEMENT inside FlexGate columns (halo2-base internals) is NOT pinned:
+ * "placement parity unpinned"; see DESIGN.md.
+ */
+#ifndef HSW_ORACLE_H
+#define HSW_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One field element, canonical (non-Montgomery) little-endian limbs. */
+typedef struct { uint64_t l[4]; } ofe_t;
+
+/* Call / constraint tallies of one oracle context (SURVEY 8a counts). */
+typedef struct {
+    uint64_t load_witness, add, neg, mul_add, load_zero;
+    uint64_t assert_equal, range_check16, range_check32, range_check_other;
+    uint64_t spread_calls, spread_limb_calls, even_odd_calls;
+    uint64_t gate_cells, chip_cells;
+} oracle_stats_t;
+
+typedef struct oracle_ctx oracle_ctx;
+
+/* Create a context for SpreadConfig::configure(num_bits_lookup,
+ * num_advice_columns) (spread.rs:32-74).  check!=0 turns on every
+ * assert_equal / range / lookup self-check.  Returns NULL on bad shape. */
+oracle_ctx *oracle_create(int num_bits_lookup, int num_advice_columns, int check);
+void oracle_destroy(oracle_ctx *c);
+
+/* Attach output buffers.  gate: capacity in cells (may be NULL to discard).
+ * dense/spread: chip columns, column c at base + c*col_stride cells, buffer
+ * row 0 == absolute chip row `row_base`.  May be NULL to discard. */
+void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap,
+                        ofe_t *dense, ofe_t *spread, size_t col_stride,
+                        uint64_t row_base);
+/* Set SpreadConfig.num_limb_sum (row_offset follows: spread.rs:228-231). */
+void oracle_set_cursor(oracle_ctx *c, uint64_t num_limb_sum);
+uint64_t oracle_get_cursor(const oracle_ctx *c);
+size_t oracle_gate_len(const oracle_ctx *c);
+void oracle_get_stats(const oracle_ctx *c, oracle_stats_t *out);
+/* 0 if no self-check has failed so far, else nonzero; msg describes the first. */
+int oracle_failed(const oracle_ctx *c, const char **msg);
+
+/* compression.rs:19-213.  Appends one block's gate cells and chip cells. */
+int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
+                              const uint32_t pre_state[8], uint32_t next_state[8]);
+
+/* n independent blocks, each with its own pre-state (batch driver used by the
+ * parity tests and by the CPU baseline).  Streams are appended block after
+ * block; the chip cursor runs on across blocks exactly as in the reference. */
+int oracle_witness_blocks(oracle_ctx *c, const uint8_t *blocks,
+                          const uint32_t *pre_states, size_t n,
+                          uint32_t *next_states);
+
+/* lib.rs:71-349 restated on values: pads `input`, pre-hashes the first
+ * precomputed_input_len bytes with plain SHA-256 (sha2::compress256), runs
+ * max_variable_byte_size/64 in-circuit compressions (zero blocks included) and
+ * selects the state after round (num_round - precomputed_round).
+ * Outputs: digest[32]; padded blocks fed to the circuit (n_blocks*64 bytes,
+ * optional); pre/next states per block (optional).  Returns 0, or nonzero if
+ * a reference assert would have fired (lib.rs:89-90,94-97,110,114-117). */
+int oracle_digest(oracle_ctx *c, const uint8_t *input, size_t input_len,
+                  size_t precomputed_input_len, size_t max_variable_byte_size,
+                  uint8_t digest[32], uint8_t *blocks_out,
+                  uint32_t *pre_states_out, uint32_t *next_states_out);
+
+/* Plain SHA-256 compression (FIPS 180-4; what sha2::compress256 computes). */
+void oracle_plain_compress(uint32_t state[8], const uint8_t block[64]);
+
+/* SpreadConfig::load table row i (spread.rs:165-194): (i, spread(i)). */
+uint64_t oracle_spread_table_entry(uint32_t i);
+
+/* Shape numbers derived by *running* one block (not from formulas). */
+int oracle_measure_shape(int num_bits_lookup, int num_advice_columns,
+                         uint64_t *gate_cells_per_block,
+                         uint64_t *limb_calls_per_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/hsw_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.  See
+hsw_oracle.h for what is restated, the assumptions and how it is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+CELL_DTYPE = np.uint64  # one cell = 4 little-endian u64 limbs (canonical Fr)
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "load_witness", "add", "neg", "mul_add", "load_zero",
+        "assert_equal", "range_check16", "range_check32", "range_check_other",
+        "spread_calls", "spread_limb_calls", "even_odd_calls",
+        "gate_cells", "chip_cells")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "hsw_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        # -march=native objects do not travel between machines: rebuild when
+        # the library is older than the source or missing.
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_uint64]
+        L.oracle_set_cursor.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_get_cursor.restype = C.c_uint64
+        L.oracle_get_cursor.argtypes = [C.c_void_p]
+        L.oracle_gate_len.restype = C.c_size_t
+        L.oracle_gate_len.argtypes = [C.c_void_p]
+        L.oracle_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.oracle_failed.restype = C.c_int
+        L.oracle_failed.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
+        L.oracle_sha256_compression.restype = C.c_int
+        L.oracle_sha256_compression.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_witness_blocks.restype = C.c_int
+        L.oracle_witness_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_digest.restype = C.c_int
+        L.oracle_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_plain_compress.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_spread_table_entry.restype = C.c_uint64
+        L.oracle_spread_table_entry.argtypes = [C.c_uint32]
+        L.oracle_measure_shape.restype = C.c_int
+        L.oracle_measure_shape.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+INIT_STATE = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                       0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
+
+
+def measure_shape(num_bits_lookup=8, num_advice_columns=2):
+    g, l = C.c_uint64(), C.c_uint64()
+    rc = lib().oracle_measure_shape(num_bits_lookup, num_advice_columns, C.byref(g), C.byref(l))
+    if rc:
+        raise RuntimeError("oracle self-check failed while measuring shape")
+    return int(g.value), int(l.value)
+
+
+class Oracle:
+    """One SpreadConfig + gate context, mirroring the reference's mutable cursors."""
+
+    def __init__(self, num_bits_lookup=8, num_advice_columns=2, check=True):
+        self.L = lib()
+        self.bits, self.ncols = num_bits_lookup, num_advice_columns
+        self.h = self.L.oracle_create(num_bits_lookup, num_advice_columns, 1 if check else 0)
+        if not self.h:
+            raise ValueError("bad shape: 16 %% num_bits_lookup must be 0 (spread.rs:37)")
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self):
+        msg = C.c_char_p()
+        if self.L.oracle_failed(self.h, C.byref(msg)):
+            raise AssertionError("oracle constraint self-check failed: " + msg.value.decode())
+
+    def stats(self):
+        s = Stats()
+        self.L.oracle_get_stats(self.h, C.byref(s))
+        return s.as_dict()
+
+    @property
+    def cursor(self):
+        return int(self.L.oracle_get_cursor(self.h))
+
+    def witness_blocks(self, blocks, pre_states, cursor0=0, want_streams=True):
+        """blocks: (n,64) u8; pre_states: (n,8) u32.  Returns dict with
+        gate (n*G,4) u64, dense/spread (ncols, rows, 4) u64, next_states (n,8) u32,
+        row_base (absolute chip row of buffer row 0)."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 64)
+        pre_states = np.ascontiguousarray(pre_states, dtype=np.uint32).reshape(-1, 8)
+        n = blocks.shape[0]
+        assert pre_states.shape[0] == n
+        G, LC = measure_shape(self.bits, self.ncols)
+        row_base = cursor0 // self.ncols
+        rows = (cursor0 % self.ncols + LC * n + self.ncols - 1) // self.ncols
+        nxt = np.zeros((n, 8), dtype=np.uint32)
+        self.L.oracle_set_cursor(self.h, cursor0)
+        if want_streams:
+            gate = np.zeros((n * G, 4), dtype=np.uint64)
+            dense = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
+            spread = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
+            self.L.oracle_set_outputs(self.h, gate.ctypes.data, gate.shape[0], dense.ctypes.data,
+                                      spread.ctypes.data, dense.shape[1], row_base)
+        else:
+            gate = dense = spread = None
+            self.L.oracle_set_outputs(self.h, None, 0, None, None, 0, 0)
+        self.L.oracle_witness_blocks(self.h, blocks.ctypes.data, pre_states.ctypes.data, n, nxt.ctypes.data)
+        self._check()
+        return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, row_base=row_base,
+                    rows=rows, gate_cells_per_block=G, limb_calls_per_block=LC)
+
+    def digest(self, message: bytes, max_variable_byte_size: int, precomputed_input_len: int = 0,
+               want_streams=False, cursor0=None):
+        """lib.rs:71-349 on values.  Returns dict(digest, blocks, pre_states, next_states[, streams])."""
+        nblk = max_variable_byte_size // 64
+        G, LC = measure_shape(self.bits, self.ncols)
+        msg = np.frombuffer(bytes(message), dtype=np.uint8).copy()
+        dig = np.zeros(32, dtype=np.uint8)
+        blocks = np.zeros((max(nblk, 1), 64), dtype=np.uint8)
+        pre = np.zeros((max(nblk, 1), 8), dtype=np.uint32)
+        nxt = np.zeros((max(nblk, 1), 8), dtype=np.uint32)
+        if cursor0 is not None:
+            self.L.oracle_set_cursor(self.h, cursor0)
+        c0 = self.cursor
+        out = {}
+        if want_streams:
+            row_base = c0 // self.ncols
+            rows = (c0 % self.ncols + LC * nblk + self.ncols - 1) // self.ncols
+            gate = np.zeros((nblk * G, 4), dtype=np.uint64)
+            dense = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
+            spread = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
+            self.L.oracle_set_outputs(self.h, gate.ctypes.data, gate.shape[0], dense.ctypes.data,
+                                      spread.ctypes.data, dense.shape[1], row_base)
+            out.update(gate=gate, dense=dense, spread=spread, row_base=row_base, rows=rows)
+        else:
+            self.L.oracle_set_outputs(self.h, None, 0, None, None, 0, 0)
+        rc = self.L.oracle_digest(self.h, msg.ctypes.data if len(msg) else None, len(msg),
+                                  precomputed_input_len, max_variable_byte_size, dig.ctypes.data,
+                                  blocks.ctypes.data, pre.ctypes.data, nxt.ctypes.data)
+        if rc >= 10:
+            raise ValueError("reference assert would fire (oracle_digest rc=%d)" % rc)
+        self._check()
+        out.update(digest=dig.tobytes(), blocks=blocks[:nblk], pre_states=pre[:nblk],
+                   next_states=nxt[:nblk])
+        return out
+
+
+def plain_compress(state, block):
+    st = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    blk = np.ascontiguousarray(block, dtype=np.uint8)
+    lib().oracle_plain_compress(st.ctypes.data, blk.ctypes.data)
+    return st
+
+
+def spread_table(num_bits_lookup=8):
+    """SpreadConfig::load (spread.rs:165-194): rows (i, spread(i))."""
+    L = lib()
+    return [(i, int(L.oracle_spread_table_entry(i))) for i in range(1 << num_bits_lookup)]
