@@ -1,0 +1,120 @@
+"""ctypes binding of libhsw.so -- the C ABI declared in include/hsw.h.
+
+The library is built in-tree by csrc/Makefile (hipcc, gfx950).  There is no
+fallback: if it is missing the import of the engine fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhsw.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+HSW_OK = 0
+HSW_ERR_INVALID_ARG = 1
+HSW_ERR_SHAPE = 2
+HSW_ERR_NO_DEVICE = 3
+HSW_ERR_HIP = 4
+HSW_ERR_UNSUPPORTED = 5
+HSW_ERR_TOO_LARGE = 6
+HSW_ERR_NOMEM = 7
+
+HSW_REPR_CANONICAL = 0
+HSW_REPR_MONTGOMERY = 1
+HSW_SKIP_GATE = 2
+HSW_SKIP_CHIP = 4
+HSW_CELL_BYTES = 32
+
+
+class Shape(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "num_bits_lookup", "num_advice_columns", "limbs_per_spread", "cells_per_spread",
+        "cells_per_state_spread", "cells_per_sigma", "cells_per_ch", "cells_per_maj",
+        "cells_per_sched_step", "cells_per_round", "off_words", "off_msg_spread", "off_sched",
+        "off_state_spread", "off_rounds", "off_feed", "gate_cells_per_block",
+        "spread_calls_per_block", "limb_calls_per_block", "chip_cells_per_block")] + [
+        ("algorithmic_bytes_per_block", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# every symbol include/hsw.h declares (tests check the library exports them all)
+SYMBOLS = (
+    "hsw_shape_query", "hsw_chip_rows", "hsw_engine_create", "hsw_engine_destroy",
+    "hsw_engine_shape", "hsw_engine_synchronize", "hsw_witness_blocks", "hsw_sha256_chain",
+    "hsw_witness_blocks_host", "hsw_last_kernel_ms", "hsw_set_timing", "hsw_strerror",
+    "hsw_last_error", "hsw_abi_version",
+)
+
+
+def build(force=False):
+    """Compile libhsw.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s"])
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libhsw.so was not produced by csrc/Makefile")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libhsw.so is missing: build it with `make -C %s` (hipcc, gfx950). "
+            "There is no CPU fallback for the witness engine." % CSRC)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, u32p = C.c_void_p, C.c_void_p, C.c_void_p
+    L.hsw_abi_version.restype = C.c_uint32
+    L.hsw_strerror.restype = C.c_char_p
+    L.hsw_strerror.argtypes = [C.c_int]
+    L.hsw_last_error.restype = C.c_char_p
+    L.hsw_last_error.argtypes = [vp]
+    L.hsw_shape_query.restype = C.c_int
+    L.hsw_shape_query.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Shape)]
+    L.hsw_chip_rows.restype = C.c_uint64
+    L.hsw_chip_rows.argtypes = [C.POINTER(Shape), C.c_uint64, C.c_uint64]
+    L.hsw_engine_create.restype = C.c_int
+    L.hsw_engine_create.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.hsw_engine_destroy.restype = None
+    L.hsw_engine_destroy.argtypes = [vp]
+    L.hsw_engine_shape.restype = C.c_int
+    L.hsw_engine_shape.argtypes = [vp, C.POINTER(Shape)]
+    L.hsw_engine_synchronize.restype = C.c_int
+    L.hsw_engine_synchronize.argtypes = [vp]
+    L.hsw_witness_blocks.restype = C.c_int
+    L.hsw_witness_blocks.argtypes = [vp, u8p, u32p, C.c_size_t, C.c_uint64, vp, vp, vp,
+                                     C.c_size_t, u32p, C.c_uint32]
+    L.hsw_sha256_chain.restype = C.c_int
+    L.hsw_sha256_chain.argtypes = [vp, u8p, C.c_size_t, C.c_size_t, u32p, u32p]
+    L.hsw_witness_blocks_host.restype = C.c_int
+    L.hsw_witness_blocks_host.argtypes = [vp, u8p, u32p, C.c_size_t, C.c_uint64, vp, vp, vp,
+                                          C.c_size_t, u32p, C.c_uint32]
+    L.hsw_last_kernel_ms.restype = C.c_int
+    L.hsw_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.hsw_set_timing.restype = C.c_int
+    L.hsw_set_timing.argtypes = [vp, C.c_int]
+    _lib = L
+    return L
+
+
+class HswError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().hsw_strerror(status).decode()
+        super().__init__("hsw status %d (%s)%s" % (status, msg, (": " + detail) if detail else ""))
+
+
+def shape_query(num_bits_lookup=8, num_advice_columns=2):
+    s = Shape()
+    rc = lib().hsw_shape_query(num_bits_lookup, num_advice_columns, C.byref(s))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return s

@@ -1,0 +1,360 @@
+// hsw_api.cpp -- the C ABI of include/hsw.h over the gfx950 kernels.
+//
+// Boundary it replaces (reference has no FFI; see include/hsw.h header):
+//   src/lib.rs:180-189 block loop -> src/compression.rs:19-25 sha256_compression.
+// There is deliberately NO CPU fallback here: without a HIP device every
+// compute entry point fails with HSW_ERR_NO_DEVICE / HSW_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/hsw.h"
+#include "hsw_kernels.h"
+#include "hsw_layout.h"
+
+struct hsw_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hsw_shape shape{};
+    int limbs = 2;
+    bool timing = false;
+    bool timed = false;        // ev0/ev1 bracket a launch
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+namespace {
+
+template <int L>
+void fill_shape(hsw_shape *s) {
+    using LY = hsw::Lay<L>;
+    s->limbs_per_spread = LY::LIMBS;
+    s->cells_per_spread = LY::S;
+    s->cells_per_state_spread = LY::S2S;
+    s->cells_per_sigma = LY::SIGMA;
+    s->cells_per_ch = LY::CH;
+    s->cells_per_maj = LY::MAJ;
+    s->cells_per_sched_step = LY::SCHED;
+    s->cells_per_round = LY::ROUND;
+    s->off_words = LY::OFF_WORDS;
+    s->off_msg_spread = LY::OFF_MSG;
+    s->off_sched = LY::OFF_SCHED;
+    s->off_state_spread = LY::OFF_STATE;
+    s->off_rounds = LY::OFF_ROUNDS;
+    s->off_feed = LY::OFF_FEED;
+    s->gate_cells_per_block = LY::GATE_CELLS;
+    s->spread_calls_per_block = LY::SPREAD_CALLS;
+    s->limb_calls_per_block = LY::LIMB_CALLS;
+    s->chip_cells_per_block = LY::CHIP_CELLS;
+    s->algorithmic_bytes_per_block =
+        ((uint64_t)LY::GATE_CELLS + (uint64_t)LY::CHIP_CELLS) * HSW_CELL_BYTES + 64 + 32 + 32;
+}
+
+int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSuccess) {
+    if (e) {
+        char buf[256];
+        if (he != hipSuccess)
+            std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(he));
+        else
+            std::snprintf(buf, sizeof buf, "%s", what);
+        e->err = buf;
+    }
+    return status;
+}
+
+// Makes the engine's device current for the scope of one call.
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t hsw_abi_version(void) { return HSW_ABI_VERSION; }
+
+const char *hsw_strerror(int status) {
+    switch (status) {
+        case HSW_OK: return "ok";
+        case HSW_ERR_INVALID_ARG: return "invalid argument";
+        case HSW_ERR_SHAPE: return "invalid shape (16 % num_bits_lookup != 0, zero columns, or size not a multiple of 64)";
+        case HSW_ERR_NO_DEVICE: return "no usable HIP device";
+        case HSW_ERR_HIP: return "HIP runtime error";
+        case HSW_ERR_UNSUPPORTED: return "not supported by this build";
+        case HSW_ERR_TOO_LARGE: return "message does not fit max_variable_byte_size";
+        case HSW_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char *hsw_last_error(const hsw_engine *e) { return e ? e->err.c_str() : ""; }
+
+int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out) {
+    if (!out) return HSW_ERR_INVALID_ARG;
+    // spread.rs:37 debug_assert_eq!(16 % num_bits_lookup, 0)
+    if (num_bits_lookup == 0 || num_bits_lookup > 16 || 16 % num_bits_lookup != 0) return HSW_ERR_SHAPE;
+    if (num_advice_columns == 0) return HSW_ERR_SHAPE;
+    std::memset(out, 0, sizeof *out);
+    out->num_bits_lookup = num_bits_lookup;
+    out->num_advice_columns = num_advice_columns;
+    switch (16 / num_bits_lookup) {
+        case 1: fill_shape<1>(out); break;
+        case 2: fill_shape<2>(out); break;
+        case 4: fill_shape<4>(out); break;
+        case 8: fill_shape<8>(out); break;
+        case 16: fill_shape<16>(out); break;
+        default: return HSW_ERR_SHAPE;
+    }
+    return HSW_OK;
+}
+
+uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) {
+    if (!s || s->num_advice_columns == 0 || s->limb_calls_per_block == 0) return 0;
+    const uint64_t nc = s->num_advice_columns;
+    return (cursor0 % nc + (uint64_t)s->limb_calls_per_block * n_blocks + nc - 1) / nc;
+}
+
+int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
+                      uint32_t num_advice_columns, hsw_engine **out) {
+    if (!out) return HSW_ERR_INVALID_ARG;
+    *out = nullptr;
+    hsw_shape shape;
+    int rc = hsw_shape_query(num_bits_lookup, num_advice_columns, &shape);
+    if (rc != HSW_OK) return rc;
+    if (shape.limbs_per_spread > 4) return HSW_ERR_UNSUPPORTED;   // kernels built for 16/8/4-bit tables
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HSW_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return HSW_ERR_NO_DEVICE;
+    hsw_engine *e = new (std::nothrow) hsw_engine();
+    if (!e) return HSW_ERR_NOMEM;
+    e->device = device;
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->shape = shape;
+    e->limbs = (int)shape.limbs_per_spread;
+    DeviceScope ds(device);
+    if (!ds.ok) { delete e; return HSW_ERR_NO_DEVICE; }
+    if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+        if (e->ev0) (void)hipEventDestroy(e->ev0);
+        delete e;
+        return HSW_ERR_HIP;
+    }
+    *out = e;
+    return HSW_OK;
+}
+
+void hsw_engine_destroy(hsw_engine *e) {
+    if (!e) return;
+    {
+        DeviceScope ds(e->device);
+        if (e->ev0) (void)hipEventDestroy(e->ev0);
+        if (e->ev1) (void)hipEventDestroy(e->ev1);
+    }
+    delete e;
+}
+
+int hsw_engine_shape(const hsw_engine *e, hsw_shape *out) {
+    if (!e || !out) return HSW_ERR_INVALID_ARG;
+    *out = e->shape;
+    return HSW_OK;
+}
+
+int hsw_engine_synchronize(hsw_engine *e) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    DeviceScope ds(e->device);
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipStreamSynchronize", he);
+    return HSW_OK;
+}
+
+int hsw_set_timing(hsw_engine *e, int enabled) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    e->timing = enabled != 0;
+    e->timed = false;
+    return HSW_OK;
+}
+
+int hsw_last_kernel_ms(hsw_engine *e, float *ms) {
+    if (!e || !ms) return HSW_ERR_INVALID_ARG;
+    if (!e->timed) return set_err(e, HSW_ERR_INVALID_ARG, "no timed launch (call hsw_set_timing(e, 1) first)");
+    DeviceScope ds(e->device);
+    hipError_t he = hipEventSynchronize(e->ev1);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventSynchronize", he);
+    he = hipEventElapsedTime(ms, e->ev0, e->ev1);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventElapsedTime", he);
+    return HSW_OK;
+}
+
+int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d_pre_states,
+                       size_t n_blocks, uint64_t spread_cursor0, void *d_gate, void *d_chip_dense,
+                       void *d_chip_spread, size_t chip_col_stride, uint32_t *d_next_states,
+                       uint32_t flags) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (n_blocks == 0) return HSW_OK;
+    if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP))
+        return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
+    if ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY)
+        return set_err(e, HSW_ERR_UNSUPPORTED, "HSW_REPR_MONTGOMERY is not built yet");
+    if (!d_blocks || !d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
+    if (((uintptr_t)d_blocks & 3u) || ((uintptr_t)d_pre_states & 3u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "inputs must be 4-byte aligned");
+    const bool want_gate = !(flags & HSW_SKIP_GATE), want_chip = !(flags & HSW_SKIP_CHIP);
+    if (want_gate && (!d_gate || ((uintptr_t)d_gate & 15u)))
+        return set_err(e, HSW_ERR_INVALID_ARG, "gate buffer null or not 16-byte aligned");
+    if (want_chip) {
+        if (!d_chip_dense || !d_chip_spread || ((uintptr_t)d_chip_dense & 15u) ||
+            ((uintptr_t)d_chip_spread & 15u))
+            return set_err(e, HSW_ERR_INVALID_ARG, "chip buffers null or not 16-byte aligned");
+        if (chip_col_stride < hsw_chip_rows(&e->shape, spread_cursor0, n_blocks))
+            return set_err(e, HSW_ERR_INVALID_ARG, "chip_col_stride smaller than hsw_chip_rows()");
+    }
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+
+    // One launch covers up to 2^20 blocks (2.5 TB of cells would be far past
+    // HBM anyway); longer batches are issued as consecutive launches.
+    const size_t CHUNK = (size_t)1 << 20;
+    hipError_t he;
+    if (e->timing) {
+        he = hipEventRecord(e->ev0, e->stream);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
+    }
+    for (size_t done = 0; done < n_blocks; done += CHUNK) {
+        const size_t n = n_blocks - done < CHUNK ? n_blocks - done : CHUNK;
+        hsw::ExpandParams p{};
+        p.blocks = d_blocks + 64 * done;
+        p.pre_states = d_pre_states + 8 * done;
+        p.gate = want_gate ? static_cast<uint8_t *>(d_gate) +
+                                 (size_t)HSW_CELL_BYTES * e->shape.gate_cells_per_block * done
+                           : nullptr;
+        // the chip pass addresses rows from the *call's* cursor0, so chunks only
+        // move the cursor forward
+        p.chip_dense = d_chip_dense;
+        p.chip_spread = d_chip_spread;
+        p.next_states = d_next_states ? d_next_states + 8 * done : nullptr;
+        p.n_blocks = n;
+        p.chip_col_stride = chip_col_stride;
+        p.cursor0 = spread_cursor0;
+        p.ncols = e->shape.num_advice_columns;
+        p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP);
+        if (done != 0) {
+            // later chunks: keep buffer row 0 fixed by pre-offsetting the column
+            // base instead of the cursor origin
+            const uint64_t nc = p.ncols;
+            const uint64_t c1 = spread_cursor0 + (uint64_t)done * e->shape.limb_calls_per_block;
+            const uint64_t row_shift = c1 / nc - spread_cursor0 / nc;
+            p.cursor0 = c1;
+            if (want_chip) {
+                p.chip_dense = static_cast<uint8_t *>(d_chip_dense) + (size_t)row_shift * HSW_CELL_BYTES;
+                p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES;
+            }
+        }
+        he = hsw::launch_expand(p, e->limbs, e->stream);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_expand_kernel", he);
+    }
+    if (e->timing) {
+        he = hipEventRecord(e->ev1, e->stream);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
+        e->timed = true;
+    }
+    return HSW_OK;
+}
+
+int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
+                     size_t blocks_per_message, const uint32_t *d_init_states,
+                     uint32_t *d_pre_states) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (n_messages == 0 || blocks_per_message == 0) return HSW_OK;
+    if (!d_blocks || !d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    if (((uintptr_t)d_blocks & 3u) || ((uintptr_t)d_pre_states & 3u) || ((uintptr_t)d_init_states & 3u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "pointers must be 4-byte aligned");
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipError_t he = hsw::launch_chain(d_blocks, n_messages, blocks_per_message, d_init_states,
+                                      d_pre_states, e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_chain_kernel", he);
+    return HSW_OK;
+}
+
+int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t *pre_states,
+                            size_t n_blocks, uint64_t spread_cursor0, void *gate, void *chip_dense,
+                            void *chip_spread, size_t chip_col_stride, uint32_t *next_states,
+                            uint32_t flags) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (n_blocks == 0) return HSW_OK;
+    if (!blocks || !pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
+    if (!gate) flags |= HSW_SKIP_GATE;
+    if (!chip_dense || !chip_spread) flags |= HSW_SKIP_CHIP;
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+
+    const size_t G = e->shape.gate_cells_per_block;
+    const size_t ncols = e->shape.num_advice_columns;
+    const size_t rows = (size_t)hsw_chip_rows(&e->shape, spread_cursor0, n_blocks);
+    if (!(flags & HSW_SKIP_CHIP) && chip_col_stride < rows)
+        return set_err(e, HSW_ERR_INVALID_ARG, "chip_col_stride smaller than hsw_chip_rows()");
+    const size_t gate_bytes = (flags & HSW_SKIP_GATE) ? 0 : n_blocks * G * HSW_CELL_BYTES;
+    const size_t col_bytes = (flags & HSW_SKIP_CHIP) ? 0 : ncols * rows * HSW_CELL_BYTES;
+
+    uint8_t *d_blocks = nullptr; uint32_t *d_pre = nullptr, *d_next = nullptr;
+    void *d_gate = nullptr, *d_cd = nullptr, *d_cs = nullptr;
+    int rc = HSW_OK;
+    hipError_t he = hipSuccess;
+    auto fail = [&](const char *what) { rc = set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, what, he); };
+    do {
+        if ((he = hipMalloc((void **)&d_blocks, n_blocks * 64)) != hipSuccess) { fail("hipMalloc blocks"); break; }
+        if ((he = hipMalloc((void **)&d_pre, n_blocks * 32)) != hipSuccess) { fail("hipMalloc pre_states"); break; }
+        if ((he = hipMalloc((void **)&d_next, n_blocks * 32)) != hipSuccess) { fail("hipMalloc next_states"); break; }
+        if (gate_bytes && (he = hipMalloc(&d_gate, gate_bytes)) != hipSuccess) { fail("hipMalloc gate"); break; }
+        if (col_bytes && (he = hipMalloc(&d_cd, col_bytes)) != hipSuccess) { fail("hipMalloc chip dense"); break; }
+        if (col_bytes && (he = hipMalloc(&d_cs, col_bytes)) != hipSuccess) { fail("hipMalloc chip spread"); break; }
+        if ((he = hipMemcpyAsync(d_blocks, blocks, n_blocks * 64, hipMemcpyHostToDevice, e->stream)) != hipSuccess) { fail("H2D blocks"); break; }
+        if ((he = hipMemcpyAsync(d_pre, pre_states, n_blocks * 32, hipMemcpyHostToDevice, e->stream)) != hipSuccess) { fail("H2D pre_states"); break; }
+        if (col_bytes) {
+            // cells of the first / last row owned by neighbouring calls must survive the round trip
+            for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
+                he = hipMemcpyAsync((uint8_t *)d_cd + c * rows * HSW_CELL_BYTES,
+                                    (const uint8_t *)chip_dense + c * chip_col_stride * HSW_CELL_BYTES,
+                                    rows * HSW_CELL_BYTES, hipMemcpyHostToDevice, e->stream);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync((uint8_t *)d_cs + c * rows * HSW_CELL_BYTES,
+                                        (const uint8_t *)chip_spread + c * chip_col_stride * HSW_CELL_BYTES,
+                                        rows * HSW_CELL_BYTES, hipMemcpyHostToDevice, e->stream);
+            }
+            if (he != hipSuccess) { fail("H2D chip columns"); break; }
+        }
+        rc = hsw_witness_blocks(e, d_blocks, d_pre, n_blocks, spread_cursor0, d_gate, d_cd, d_cs, rows, d_next, flags);
+        if (rc != HSW_OK) break;
+        if (gate_bytes && (he = hipMemcpyAsync(gate, d_gate, gate_bytes, hipMemcpyDeviceToHost, e->stream)) != hipSuccess) { fail("D2H gate"); break; }
+        if (col_bytes) {
+            for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
+                he = hipMemcpyAsync((uint8_t *)chip_dense + c * chip_col_stride * HSW_CELL_BYTES,
+                                    (uint8_t *)d_cd + c * rows * HSW_CELL_BYTES, rows * HSW_CELL_BYTES,
+                                    hipMemcpyDeviceToHost, e->stream);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync((uint8_t *)chip_spread + c * chip_col_stride * HSW_CELL_BYTES,
+                                        (uint8_t *)d_cs + c * rows * HSW_CELL_BYTES, rows * HSW_CELL_BYTES,
+                                        hipMemcpyDeviceToHost, e->stream);
+            }
+            if (he != hipSuccess) { fail("D2H chip columns"); break; }
+        }
+        if (next_states && (he = hipMemcpyAsync(next_states, d_next, n_blocks * 32, hipMemcpyDeviceToHost, e->stream)) != hipSuccess) { fail("D2H next_states"); break; }
+        if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) { fail("hipStreamSynchronize"); break; }
+    } while (0);
+    if (rc != HSW_OK) (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(d_blocks); (void)hipFree(d_pre); (void)hipFree(d_next);
+    (void)hipFree(d_gate); (void)hipFree(d_cd); (void)hipFree(d_cs);
+    return rc;
+}
+
+}  // extern "C"

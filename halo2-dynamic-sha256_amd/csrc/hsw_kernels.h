@@ -1,0 +1,39 @@
+// hsw_kernels.h -- internal launch interface between the C ABI (hsw_api.cpp)
+// and the gfx950 kernels (hsw_kernels.hip).  Not part of the public boundary.
+#ifndef HSW_KERNELS_H
+#define HSW_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hsw {
+
+enum : uint32_t {
+    HSW_K_MONTGOMERY = 1u,   // mirrors HSW_REPR_MONTGOMERY
+    HSW_K_SKIP_GATE = 2u,    // mirrors HSW_SKIP_GATE
+    HSW_K_SKIP_CHIP = 4u,    // mirrors HSW_SKIP_CHIP
+};
+
+struct ExpandParams {
+    const uint8_t *blocks;        // n_blocks * 64 bytes
+    const uint32_t *pre_states;   // n_blocks * 8
+    void *gate;                   // n_blocks * G cells of 32 B
+    void *chip_dense;             // ncols columns, chip_col_stride cells apart
+    void *chip_spread;
+    uint32_t *next_states;        // n_blocks * 8, may be null
+    size_t n_blocks;
+    size_t chip_col_stride;       // cells
+    uint64_t cursor0;             // SpreadConfig.num_limb_sum before block 0
+    uint32_t ncols;               // num_advice_columns
+    uint32_t flags;               // HSW_K_*
+};
+
+// limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count
+// this build has no instantiation for.
+hipError_t launch_expand(const ExpandParams &p, int limbs, hipStream_t stream);
+hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_per_message,
+                        const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
+
+}  // namespace hsw
+#endif

@@ -1,0 +1,629 @@
+// hsw_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the SHA-256 witness engine.
+//
+// One 64-lane wavefront per message block (workgroup = one wave).
+//
+//  chain phase   the plain SHA-256 recurrence of the block (W[0..63], and the
+//                a/e values born in every round) is computed once, wave-uniform,
+//                and staged in LDS (sW, sA, sE).  From these seeds every unit of
+//                the gadget (a schedule step, a round, ...) is independent.
+//  expand phase  lane = unit.  Every lane runs the same straight-line program --
+//                the reference's gate-call sequence for that unit
+//                (compression.rs:57-96 for a schedule step, :125-196 for a
+//                round) -- and appends each gate cell to its own row of a
+//                [64][T] LDS tile (64-bit values; spread/dense conversions are
+//                shift/mask bit interleaves, no table reads).  When a tile is
+//                full the wave transposes it out: for every row, 64 lanes store
+//                64 consecutive 16-byte pieces (= T/… cells x 32 B), i.e. one
+//                fully contiguous 1 KiB global_store_dwordx4 per instruction.
+//                Emission offsets and flush points are compile-time constants
+//                after inlining, so an emitted cell is a single ds_write_b64
+//                with an immediate offset.
+//  chip pass     the 16-bit dense input of every SpreadConfig::spread call is
+//                staged in LDS (2,060 per block); at the end of the block the
+//                chip columns denses[c] / spreads[c] (spread.rs:196-233) are
+//                written as contiguous column runs.
+//
+// Pure 32/64-bit integer work, write-streaming: the bound is HBM write
+// bandwidth (DESIGN.md "Roofline").  No MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hsw_kernels.h"
+#include "hsw_layout.h"
+
+namespace hsw {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef unsigned short u16;
+
+// FIPS 180-4 round constants (reference compression.rs:992-1001: K enters the
+// circuit as a gate constant).
+__constant__ u32 K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __constant__ u32 IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                                        0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+// BN254 Fr modulus p, 32-bit little-endian limbs.  -x for 0 < x <= 0x55555555
+// only touches limb 0: p[0] = 0xf0000001 > x, so there is no borrow.
+#define HSW_P0 0xf0000001u
+#define HSW_P1 0x43e1f593u
+#define HSW_P2 0x79b97091u
+#define HSW_P3 0x2833e848u
+#define HSW_P4 0x8181585du
+#define HSW_P5 0xb85045b6u
+#define HSW_P6 0xe131a029u
+#define HSW_P7 0x30644e72u
+
+#define DEV __device__ __forceinline__
+
+DEV u32 rotr32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// dense 16 bits -> 32 bits with bit i at position 2i (the "spread" form,
+// reference spread.rs:211-218 / table rows of :165-194), by shifts and masks.
+DEV u32 spread16(u32 x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+DEV u64 spread32(u32 x) { return (u64)spread16(x) | ((u64)spread16(x >> 16) << 32); }
+// even-position bits of a 32-bit value packed into 16 bits
+// (decompose_even_and_odd_unchecked, spread.rs:146-157; odd = even_bits(x >> 1)).
+DEV u32 even_bits(u32 x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+
+// ------------------------------------------------------------------ emitter
+// Per-lane emission state.  Everything except `row`, `active` and `call` is
+// wave-uniform and, after inlining, a compile-time constant at every use.
+template <int T>
+struct Em {
+    u64 *row;          // this lane's tile row (LDS)
+    const u64 *tile;   // tile base (LDS)
+    u16 *d16;          // staged dense inputs of spread() calls (LDS)
+    uint4 *out;        // this block's gate stream, in 16-byte pieces
+    u32 pos;           // cells currently in the tile
+    u32 negmask;       // tile positions that hold a field negation (-x)
+    u32 nrows;         // units (rows) of the current phase
+    u32 unit_cells;    // gate cells per unit
+    u32 cell_base;     // cell index (in block) of unit 0, tile column 0
+    u32 call;          // this lane's next spread-call slot (index into d16)
+    bool active;       // lane < nrows
+    bool write_gate;   // HSW_SKIP_GATE not set
+};
+
+// Transpose `ncells` tile columns out to HBM: row r goes to cells
+// [cell_base + r*unit_cells, +ncells).  Lane pairs cover one 32-byte cell
+// (low / high 16 bytes), so a wave-wide store instruction writes 1 KiB
+// contiguous when ncells*2 >= 64.
+template <int T>
+DEV void flush_tile(Em<T> &em, u32 ncells) {
+    __syncthreads();
+    if (em.write_gate) {
+        const u32 lane = threadIdx.x;
+        const u32 ppr = 2u * ncells;          // 16-byte pieces per row
+        const u32 total = em.nrows * ppr;
+#pragma unroll 4
+        for (u32 i = lane; i < total; i += 64) {
+            const u32 r = i / ppr;
+            const u32 q = i - r * ppr;
+            const u32 p = q >> 1, h = q & 1u;
+            const u64 v = em.tile[r * (T + 1) + p];
+            const u32 lo = (u32)v, hi = (u32)(v >> 32);
+            uint4 o;
+            o.x = h ? 0u : lo;
+            o.y = h ? 0u : hi;
+            o.z = 0u;
+            o.w = 0u;
+            if (em.negmask != 0u) {
+                if (((em.negmask >> p) & 1u) && v != 0ull) {
+                    // cell holds p - x (neg gate, compression.rs:320-321), x < 2^31
+                    o.x = h ? HSW_P4 : (HSW_P0 - lo);
+                    o.y = h ? HSW_P5 : HSW_P1;
+                    o.z = h ? HSW_P6 : HSW_P2;
+                    o.w = h ? HSW_P7 : HSW_P3;
+                }
+            }
+            em.out[(size_t)(em.cell_base + r * em.unit_cells + p) * 2u + h] = o;
+        }
+    }
+    __syncthreads();
+    em.cell_base += ncells;
+    em.pos = 0;
+    em.negmask = 0;
+}
+
+template <int T>
+DEV void emit(Em<T> &em, u64 v) {
+    em.row[em.pos] = v;
+    if (++em.pos == (u32)T) flush_tile<T>(em, T);
+}
+// cell whose field value is -x (x small): stored as x plus a tile-position flag
+template <int T>
+DEV void emit_neg(Em<T> &em, u64 x) {
+    em.negmask |= 1u << em.pos;
+    emit<T>(em, x);
+}
+
+template <int T>
+DEV void phase_begin(Em<T> &em, u32 nrows, u32 unit_cells, u32 cell_base, u32 call_base,
+                     u32 calls_per_unit) {
+    const u32 lane = threadIdx.x;
+    em.nrows = nrows;
+    em.unit_cells = unit_cells;
+    em.cell_base = cell_base;
+    em.pos = 0;
+    em.negmask = 0;
+    em.active = lane < nrows;
+    em.call = call_base + (lane < nrows ? lane : nrows - 1) * calls_per_unit;
+}
+template <int T>
+DEV void phase_end(Em<T> &em) {
+    if (em.pos != 0) flush_tile<T>(em, em.pos);
+}
+
+// ---------------------------------------------------- halo2-base gate cells
+// (cell orders: DESIGN.md assumption A1)
+template <int T> DEV void g_lw(Em<T> &em, u64 v) { emit<T>(em, v); }                 // [v]
+template <int T> DEV u64 g_add(Em<T> &em, u64 a, u64 b) {                            // [a, b, 1, a+b]
+    const u64 r = a + b;
+    emit<T>(em, a); emit<T>(em, b); emit<T>(em, 1); emit<T>(em, r);
+    return r;
+}
+// mul_add(a, b, c) = a*b + c -> [c, a, b, out]; `out` is passed in (computed by
+// shifts by the caller: every b is a power of two or a 3-term sum of them).
+template <int T> DEV void g_mul_add(Em<T> &em, u64 a, u64 b, u64 c, u64 out) {
+    emit<T>(em, c); emit<T>(em, a); emit<T>(em, b); emit<T>(em, out);
+}
+
+// ------------------------------------------------------- spread.rs mirrors
+// SpreadConfig::spread (spread.rs:76-123) on a 16-bit dense value.
+template <int L, int T>
+DEV u32 sc_spread(Em<T> &em, u32 dense) {
+    constexpr int B = 16 / L;
+    constexpr u32 MASK = (1u << B) - 1u;
+    if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced in the chip pass
+    em.call++;
+#pragma unroll
+    for (int j = 0; j < L; j++) g_lw<T>(em, (dense >> (B * j)) & MASK);              // :86-88
+    u32 sum = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {                                                    // :91-98
+        const u32 limb = (dense >> (B * j)) & MASK;
+        const u32 ns = sum | (limb << (B * j));
+        g_mul_add<T>(em, limb, 1u << (B * j), sum, ns);
+        sum = ns;
+    }
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {                                                    // :112-121
+        const u32 limb = (dense >> (B * j)) & MASK;
+        const u32 sl = spread16(limb);
+        g_lw<T>(em, sl);                                                             // spread_limb :225
+        const u32 na = acc | (sl << (2 * B * j));
+        g_mul_add<T>(em, sl, (u64)1 << (2 * B * j), acc, na);
+        acc = na;
+    }
+    return acc;
+}
+
+// state_to_spread_u32 (compression.rs:215-246)
+template <int L, int T>
+DEV void state_to_spread(Em<T> &em, u32 x) {
+    const u32 lo = x & 0xffffu, hi = x >> 16;
+    g_lw<T>(em, lo);                                     // :230
+    g_lw<T>(em, hi);                                     // :231
+    g_mul_add<T>(em, hi, 1u << 16, lo, x);               // :232-237
+    sc_spread<L, T>(em, lo);                             // :243
+    sc_spread<L, T>(em, hi);                             // :244
+}
+
+// mod_u32 (compression.rs:266-295); x < 2^35
+template <int T>
+DEV u32 mod_u32(Em<T> &em, u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    g_lw<T>(em, lo);                                     // :280
+    g_lw<T>(em, hi);                                     // :281
+    g_mul_add<T>(em, hi, (u64)1 << 32, lo, x);           // :283-288
+    return lo;
+}
+
+// { spread(even); spread(odd); 2*odd_spread + even_spread } (compression.rs:344-354 etc.)
+template <int L, int T>
+DEV void recheck_even_odd(Em<T> &em, u32 even, u32 odd) {
+    const u32 es = sc_spread<L, T>(em, even);
+    const u32 os = sc_spread<L, T>(em, odd);
+    g_mul_add<T>(em, 2, os, es, (u64)es + 2ull * (u64)os);
+}
+
+// sigma_generic (compression.rs:702-882).  S1..S3 are STARTS[1..3]; SHa/SHb/SHc
+// the three shifts of coeffs[i] (a shift of 64 = term absent: sigma_lower drops
+// the wrapped piece, :658,:685).
+struct SigmaUpper0 {   // :600-608
+    static constexpr int S1 = 2, S2 = 13, S3 = 22;
+    static constexpr u64 C0 = (1ull << 60) + (1ull << 38) + (1ull << 20);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 42) + (1ull << 24);
+    static constexpr u64 C2 = (1ull << 22) + (1ull << 0) + (1ull << 46);
+    static constexpr u64 C3 = (1ull << 40) + (1ull << 18) + (1ull << 0);
+};
+struct SigmaUpper1 {   // :627-635
+    static constexpr int S1 = 6, S2 = 11, S3 = 25;
+    static constexpr u64 C0 = (1ull << 52) + (1ull << 42) + (1ull << 14);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 54) + (1ull << 26);
+    static constexpr u64 C2 = (1ull << 10) + (1ull << 0) + (1ull << 36);
+    static constexpr u64 C3 = (1ull << 38) + (1ull << 28) + (1ull << 0);
+};
+struct SigmaLower0 {   // :654-662
+    static constexpr int S1 = 3, S2 = 7, S3 = 18;
+    static constexpr u64 C0 = (1ull << 50) + (1ull << 28);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 56) + (1ull << 34);
+    static constexpr u64 C2 = (1ull << 8) + (1ull << 0) + (1ull << 42);
+    static constexpr u64 C3 = (1ull << 30) + (1ull << 22) + (1ull << 0);
+};
+struct SigmaLower1 {   // :681-689
+    static constexpr int S1 = 10, S2 = 17, S3 = 19;
+    static constexpr u64 C0 = (1ull << 30) + (1ull << 26);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 50) + (1ull << 46);
+    static constexpr u64 C2 = (1ull << 14) + (1ull << 0) + (1ull << 60);
+    static constexpr u64 C3 = (1ull << 18) + (1ull << 4) + (1ull << 0);
+};
+
+template <class SG, int L, int T>
+DEV u32 sigma_generic(Em<T> &em, u32 x) {
+    const u64 X = spread32(x);                               // x_spread.1 * 2^32 + x_spread.0
+    // :719-734 the four pieces, spread bits [2*start, 2*end) shifted to 0
+    const u64 pa = X & ((1ull << (2 * SG::S1)) - 1);
+    const u64 pb = (X >> (2 * SG::S1)) & ((1ull << (2 * (SG::S2 - SG::S1))) - 1);
+    const u64 pc = (X >> (2 * SG::S2)) & ((1ull << (2 * (SG::S3 - SG::S2))) - 1);
+    const u64 pd = X >> (2 * SG::S3);
+    g_lw<T>(em, pa); g_lw<T>(em, pb); g_lw<T>(em, pc); g_lw<T>(em, pd);
+    // :736-754 recomposition
+    u64 sum = pa, ns;
+    ns = sum + (pb << (2 * SG::S1)); g_mul_add<T>(em, pb, 1ull << (2 * SG::S1), sum, ns); sum = ns;
+    ns = sum + (pc << (2 * SG::S2)); g_mul_add<T>(em, pc, 1ull << (2 * SG::S2), sum, ns); sum = ns;
+    ns = sum + (pd << (2 * SG::S3)); g_mul_add<T>(em, pd, 1ull << (2 * SG::S3), sum, ns); sum = ns;
+    // :755-760 x_composed
+    g_mul_add<T>(em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
+    // :780-808 r_spread = sum coeff_i * piece_i  (< 2^64 by construction)
+    u64 r = 0, nr;
+    nr = r + SG::C0 * pa; g_mul_add<T>(em, SG::C0, pa, r, nr); r = nr;
+    nr = r + SG::C1 * pb; g_mul_add<T>(em, SG::C1, pb, r, nr); r = nr;
+    nr = r + SG::C2 * pc; g_mul_add<T>(em, SG::C2, pc, r, nr); r = nr;
+    nr = r + SG::C3 * pd; g_mul_add<T>(em, SG::C3, pd, r, nr); r = nr;
+    // :811-836
+    const u32 r_lo = (u32)r, r_hi = (u32)(r >> 32);
+    g_lw<T>(em, r_lo); g_lw<T>(em, r_hi);
+    g_mul_add<T>(em, r_hi, 1ull << 32, r_lo, r);
+    // :843-846
+    const u32 lo_even = even_bits(r_lo), lo_odd = even_bits(r_lo >> 1);
+    const u32 hi_even = even_bits(r_hi), hi_odd = even_bits(r_hi >> 1);
+    g_lw<T>(em, lo_even); g_lw<T>(em, lo_odd);
+    g_lw<T>(em, hi_even); g_lw<T>(em, hi_odd);
+    recheck_even_odd<L, T>(em, lo_even, lo_odd);             // :852-862
+    recheck_even_odd<L, T>(em, hi_even, hi_odd);             // :863-873
+    const u32 out = (hi_even << 16) | lo_even;
+    g_mul_add<T>(em, hi_even, 1u << 16, lo_even, out);       // :874-879
+    return out;
+}
+
+// ch (compression.rs:297-405); x, y, z are the dense words e, f, g
+template <int L, int T>
+DEV u32 ch_gadget(Em<T> &em, u32 x, u32 y, u32 z) {
+    const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
+    const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
+    const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
+    const u32 MASK_EVEN_32 = 0x55555555u;
+    const u32 p_lo = (u32)g_add<T>(em, x_lo, y_lo);          // :309-313
+    const u32 p_hi = (u32)g_add<T>(em, x_hi, y_hi);          // :314-318
+    // neg: [a, -a, 1, 0]                                       :320-321
+    emit<T>(em, x_lo); emit_neg<T>(em, x_lo); emit<T>(em, 1); emit<T>(em, 0);
+    emit<T>(em, x_hi); emit_neg<T>(em, x_hi); emit<T>(em, 1); emit<T>(em, 0);
+    // three_add(Constant(MASK), -x, z)                         :322-335, :521-530
+    const u32 t_lo = MASK_EVEN_32 - x_lo;
+    emit<T>(em, MASK_EVEN_32); emit_neg<T>(em, x_lo); emit<T>(em, 1); emit<T>(em, t_lo);
+    const u32 q_lo = (u32)g_add<T>(em, t_lo, z_lo);
+    const u32 t_hi = MASK_EVEN_32 - x_hi;
+    emit<T>(em, MASK_EVEN_32); emit_neg<T>(em, x_hi); emit<T>(em, 1); emit<T>(em, t_hi);
+    const u32 q_hi = (u32)g_add<T>(em, t_hi, z_hi);
+    // :336-343 four even/odd splits before any re-check
+    const u32 p_lo_even = even_bits(p_lo), p_lo_odd = even_bits(p_lo >> 1);
+    const u32 p_hi_even = even_bits(p_hi), p_hi_odd = even_bits(p_hi >> 1);
+    const u32 q_lo_even = even_bits(q_lo), q_lo_odd = even_bits(q_lo >> 1);
+    const u32 q_hi_even = even_bits(q_hi), q_hi_odd = even_bits(q_hi >> 1);
+    g_lw<T>(em, p_lo_even); g_lw<T>(em, p_lo_odd);
+    g_lw<T>(em, p_hi_even); g_lw<T>(em, p_hi_odd);
+    g_lw<T>(em, q_lo_even); g_lw<T>(em, q_lo_odd);
+    g_lw<T>(em, q_hi_even); g_lw<T>(em, q_hi_odd);
+    recheck_even_odd<L, T>(em, p_lo_even, p_lo_odd);         // :344-354
+    recheck_even_odd<L, T>(em, p_hi_even, p_hi_odd);         // :355-365
+    recheck_even_odd<L, T>(em, q_lo_even, q_lo_odd);         // :366-376
+    recheck_even_odd<L, T>(em, q_hi_even, q_hi_odd);         // :377-387
+    const u32 out_lo = (u32)g_add<T>(em, p_lo_odd, q_lo_odd);    // :388-392
+    const u32 out_hi = (u32)g_add<T>(em, p_hi_odd, q_hi_odd);    // :393-397
+    const u32 out = (out_hi << 16) + out_lo;
+    g_mul_add<T>(em, out_hi, 1u << 16, out_lo, out);         // :398-403
+    return out;
+}
+
+// maj (compression.rs:460-519)
+template <int L, int T>
+DEV u32 maj_gadget(Em<T> &em, u32 x, u32 y, u32 z) {
+    const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
+    const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
+    const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
+    u64 t = g_add<T>(em, x_lo, y_lo);
+    const u32 m_lo = (u32)g_add<T>(em, t, z_lo);             // :472-478
+    t = g_add<T>(em, x_hi, y_hi);
+    const u32 m_hi = (u32)g_add<T>(em, t, z_hi);             // :479-485
+    const u32 m_lo_even = even_bits(m_lo), m_lo_odd = even_bits(m_lo >> 1);
+    const u32 m_hi_even = even_bits(m_hi), m_hi_odd = even_bits(m_hi >> 1);
+    g_lw<T>(em, m_lo_even); g_lw<T>(em, m_lo_odd);           // :486-487
+    g_lw<T>(em, m_hi_even); g_lw<T>(em, m_hi_odd);           // :488-489
+    recheck_even_odd<L, T>(em, m_lo_even, m_lo_odd);         // :490-500
+    recheck_even_odd<L, T>(em, m_hi_even, m_hi_odd);         // :501-511
+    const u32 out = (m_hi_odd << 16) | m_lo_odd;
+    g_mul_add<T>(em, m_hi_odd, 1u << 16, m_lo_odd, out);     // :512-517
+    return out;
+}
+
+// --------------------------------------------------------------- the kernel
+template <int L, int T>
+__global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
+    using LY = Lay<L>;
+    __shared__ u64 s_tile[64 * (T + 1)];
+    __shared__ u32 sW[64];
+    __shared__ u32 sA[68];     // sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
+    __shared__ u32 sE[68];     // sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
+    __shared__ u16 s_d16[(LY::SPREAD_CALLS + 3) & ~3];
+
+    const u32 lane = threadIdx.x;
+    const size_t blk = blockIdx.x;
+
+    // ---- chain phase: plain SHA-256 of this block, wave-uniform -------------
+    {
+        const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
+        const u32 *ps = p.pre_states + 8 * blk;
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            w[i] = __builtin_bswap32(bw[i]);                 // big-endian words (compression.rs:31-47)
+            if (lane == 0) sW[i] = w[i];
+        }
+        u32 a = ps[0], b = ps[1], c = ps[2], d = ps[3], e = ps[4], f = ps[5], g = ps[6], h = ps[7];
+        if (lane == 0) {
+            sA[0] = d; sA[1] = c; sA[2] = b; sA[3] = a;
+            sE[0] = h; sE[1] = g; sE[2] = f; sE[3] = e;
+        }
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                const u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                const u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+                if (lane == 0) sW[t] = w[t & 15];
+            }
+            const u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+            const u32 chv = (e & f) ^ (~e & g);
+            const u32 t1 = h + S1 + chv + K256[t] + w[t & 15];
+            const u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+            const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+            const u32 t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+            if (lane == 0) { sA[t + 4] = a; sE[t + 4] = e; }
+        }
+        if (p.next_states != nullptr && lane == 0) {
+            u32 *ns = p.next_states + 8 * blk;               // compression.rs:197-212
+            ns[0] = ps[0] + a; ns[1] = ps[1] + b; ns[2] = ps[2] + c; ns[3] = ps[3] + d;
+            ns[4] = ps[4] + e; ns[5] = ps[5] + f; ns[6] = ps[6] + g; ns[7] = ps[7] + h;
+        }
+    }
+    __syncthreads();
+
+    Em<T> em;
+    em.tile = s_tile;
+    em.row = s_tile + lane * (T + 1);
+    em.d16 = s_d16;
+    em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)blk * (size_t)LY::GATE_CELLS * 2u;
+    em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
+
+    // pre-state word i: a..d live in sA[3..0], e..h in sE[3..0]
+    auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };
+
+    // ---- words: compression.rs:31-47, 16 units of 4 mul_add ----------------
+    phase_begin<T>(em, 16, LY::WORD, LY::OFF_WORDS, 0, 0);
+    {
+        const u32 word = sW[lane & 15];
+        u32 sum = 0;
+#pragma unroll
+        for (int idx = 0; idx < 4; idx++) {                  // bytes[3 - idx] * 2^(8 idx) + sum
+            const u32 byte = (word >> (8 * idx)) & 0xffu;
+            const u32 ns = sum | (byte << (8 * idx));
+            g_mul_add<T>(em, byte, 1u << (8 * idx), sum, ns);
+            sum = ns;
+        }
+    }
+    phase_end<T>(em);
+
+    // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
+    phase_begin<T>(em, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S);
+    state_to_spread<L, T>(em, sW[lane & 15]);
+    phase_end<T>(em);
+
+    // ---- schedule: compression.rs:57-96, 48 units --------------------------
+    phase_begin<T>(em, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED);
+    {
+        const u32 idx = 16 + (lane < 48 ? lane : 47);
+        const u32 w2 = sW[idx - 2], w15 = sW[idx - 15], w7 = sW[idx - 7], w16 = sW[idx - 16];
+        const u32 term1 = sigma_generic<SigmaLower1, L, T>(em, w2);      // :60
+        const u32 term3 = sigma_generic<SigmaLower0, L, T>(em, w15);     // :61
+        u64 sum = g_add<T>(em, term1, w7);                               // :65-69
+        sum = g_add<T>(em, sum, term3);                                  // :70-74
+        sum = g_add<T>(em, sum, w16);                                    // :75-79
+        const u32 new_w = mod_u32<T>(em, sum);                           // :80
+        state_to_spread<L, T>(em, new_w);                                // :90
+    }
+    phase_end<T>(em);
+
+    // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
+    phase_begin<T>(em, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S);
+    {
+        const u32 j = lane < 6 ? lane : 5;
+        state_to_spread<L, T>(em, pre_word(j < 3 ? j : j + 1));
+    }
+    phase_end<T>(em);
+
+    // ---- 64 rounds: compression.rs:125-196 ---------------------------------
+    phase_begin<T>(em, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND);
+    {
+        const u32 r = lane;
+        const u32 a = sA[r + 3], b = sA[r + 2], c = sA[r + 1], d = sA[r];
+        const u32 e = sE[r + 3], f = sE[r + 2], g = sE[r + 1], h = sE[r];
+        const u32 sig1 = sigma_generic<SigmaUpper1, L, T>(em, e);        // :130
+        const u32 chv = ch_gadget<L, T>(em, e, f, g);                    // :131
+        u64 s = g_add<T>(em, h, sig1);                                   // :138-142
+        s = g_add<T>(em, s, chv);                                        // :143-147
+        s = g_add<T>(em, s, K256[r]);                                    // :148-152
+        s = g_add<T>(em, s, sW[r]);                                      // :153-157
+        const u32 t1 = mod_u32<T>(em, s);                                // :158
+        const u32 sig0 = sigma_generic<SigmaUpper0, L, T>(em, a);        // :164
+        const u32 mjv = maj_gadget<L, T>(em, a, b, c);                   // :165
+        s = g_add<T>(em, sig0, mjv);                                     // :166-170
+        const u32 t2 = mod_u32<T>(em, s);                                // :171
+        s = g_add<T>(em, d, t1);                                         // :181
+        const u32 e_new = mod_u32<T>(em, s);                             // :182
+        state_to_spread<L, T>(em, e_new);                                // :184
+        s = g_add<T>(em, t1, t2);                                        // :192
+        const u32 a_new = mod_u32<T>(em, s);                             // :193
+        state_to_spread<L, T>(em, a_new);                                // :195
+    }
+    phase_end<T>(em);
+
+    // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
+    phase_begin<T>(em, 8, LY::FEED, LY::OFF_FEED, 0, 0);
+    {
+        const u32 i = lane & 7;
+        const u32 x = i < 4 ? sA[67 - i] : sE[71 - i];
+        const u64 s = g_add<T>(em, x, pre_word(i));
+        mod_u32<T>(em, s);
+    }
+    phase_end<T>(em);
+
+    // ---- chip pass: spread.rs:196-233 column placement ---------------------
+    // limb call n (absolute, counted from SpreadConfig.num_limb_sum = 0) lands
+    // in column n % ncols, row n / ncols; buffer row 0 = row cursor0 / ncols.
+    if ((p.flags & HSW_K_SKIP_CHIP) == 0u) {
+        constexpr int B = LY::LIMB_BITS;
+        constexpr u32 MASK = (1u << B) - 1u;
+        const u64 ncols = p.ncols;
+        const u64 first = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
+        const u64 last = first + (u64)LY::LIMB_CALLS - 1;               // last one
+        const u64 row0 = p.cursor0 / ncols;
+        uint4 *cd = reinterpret_cast<uint4 *>(p.chip_dense);
+        uint4 *cs = reinterpret_cast<uint4 *>(p.chip_spread);
+        for (u64 c = 0; c < ncols; c++) {
+            if (last < c) continue;
+            const u64 row_lo = (first + ncols - 1 - c) / ncols;         // first row with row*ncols + c >= first
+            const u64 row_hi = (last - c) / ncols;                      // last row with row*ncols + c <= last
+            if (row_hi < row_lo) continue;
+            const u32 count = (u32)(row_hi - row_lo + 1);
+            const u32 n0 = (u32)(row_lo * ncols + c - first);           // block-relative limb index of row_lo
+            const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
+            for (u32 i = lane; i < 2u * count; i += 64) {
+                const u32 k = i >> 1, hpart = i & 1u;
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)s_d16[call] >> (B * j)) & MASK;
+                uint4 od, os;
+                od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
+                os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
+                cd[base + i] = od;
+                cs[base + i] = os;
+            }
+        }
+    }
+}
+
+// Plain SHA-256 chain pre-pass: one thread per message (hsw.h hsw_sha256_chain).
+__global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, size_t n_messages,
+                                                       size_t bpm, const u32 *init_states,
+                                                       u32 *pre_states) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_messages) return;
+    u32 st[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[i] = init_states ? init_states[8 * m + i] : IV256[i];
+    for (size_t j = 0; j < bpm; j++) {
+        const size_t blk = m * bpm + j;
+        const u32 *bw = reinterpret_cast<const u32 *>(blocks + 64 * blk);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pre_states[8 * blk + i] = st[i];
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32(bw[i]);
+        u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                const u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                const u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+            }
+            const u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+            const u32 chv = (e & f) ^ (~e & g);
+            const u32 t1 = h + S1 + chv + K256[t] + w[t & 15];
+            const u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+            const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+            const u32 t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+        st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+    }
+}
+
+// ------------------------------------------------------------------ launch
+template <int L>
+static hipError_t launch_expand_L(const ExpandParams &p, hipStream_t stream) {
+    constexpr int T = 32;
+    if (p.n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((hsw_expand_kernel<L, T>), dim3((unsigned)p.n_blocks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand(const ExpandParams &p, int limbs, hipStream_t stream) {
+    switch (limbs) {
+        case 1: return launch_expand_L<1>(p, stream);
+        case 2: return launch_expand_L<2>(p, stream);
+        case 4: return launch_expand_L<4>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t bpm,
+                        const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream) {
+    if (n_messages == 0 || bpm == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_messages + 63) / 64);
+    hipLaunchKernelGGL(hsw_chain_kernel, dim3(grid), dim3(64), 0, stream, blocks, n_messages, bpm,
+                       init_states, pre_states);
+    return hipGetLastError();
+}
+
+}  // namespace hsw

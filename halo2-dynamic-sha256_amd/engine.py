@@ -1,0 +1,115 @@
+"""Device-memory plumbing over the C ABI (include/hsw.h).
+
+PyTorch is used here only for HBM allocations, streams and (in bench.py)
+torch.distributed; all computation happens in libhsw.so's gfx950 kernels.
+Tensors that carry u32 words are int32, tensors that carry field cells are
+int64 with a trailing dimension of 4 (little-endian limbs): same bits, and
+`.view(np.uint64)` on the host side recovers the unsigned view.
+"""
+import ctypes as C
+
+from . import _native as N
+
+
+class WitnessEngine:
+    """One hsw_engine bound to (device, stream).
+
+    Mirrors how the reference is driven: SpreadConfig::configure's two shape
+    parameters (spread.rs:32-36) are fixed at construction; the mutable
+    num_limb_sum cursor (spread.rs:26) is an explicit argument of every call.
+    """
+
+    def __init__(self, device=0, num_bits_lookup=8, num_advice_columns=2, stream=None):
+        import torch  # plumbing only
+        self.torch = torch
+        self.lib = N.lib()
+        if not torch.cuda.is_available():
+            raise N.HswError(N.HSW_ERR_NO_DEVICE, "torch sees no HIP device; the witness engine has no CPU path")
+        self.device = torch.device("cuda", device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.stream = stream
+        h = C.c_void_p()
+        rc = self.lib.hsw_engine_create(device, C.c_void_p(stream.cuda_stream), num_bits_lookup,
+                                        num_advice_columns, C.byref(h))
+        if rc != N.HSW_OK:
+            raise N.HswError(rc)
+        self.h = h
+        s = N.Shape()
+        self._ok(self.lib.hsw_engine_shape(self.h, C.byref(s)))
+        self.shape = s
+        self.G = int(s.gate_cells_per_block)
+        self.ncols = int(s.num_advice_columns)
+        self.limb_calls = int(s.limb_calls_per_block)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsw_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ok(self, rc):
+        if rc != N.HSW_OK:
+            raise N.HswError(rc, self.lib.hsw_last_error(self.h).decode())
+
+    # ---- sizes -----------------------------------------------------------
+    def chip_rows(self, cursor0, n_blocks):
+        return int(self.lib.hsw_chip_rows(C.byref(self.shape), cursor0, n_blocks))
+
+    def alloc_outputs(self, n_blocks, cursor0=0):
+        """Allocate the three output buffers for n_blocks blocks in HBM."""
+        t = self.torch
+        rows = self.chip_rows(cursor0, n_blocks)
+        gate = t.empty((n_blocks * self.G, 4), dtype=t.int64, device=self.device)
+        dense = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
+        spread = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
+        nxt = t.empty((n_blocks, 8), dtype=t.int32, device=self.device)
+        return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, rows=rows)
+
+    # ---- the hot path ----------------------------------------------------
+    def witness_blocks(self, blocks, pre_states, cursor0=0, out=None, flags=0):
+        """blocks: cuda uint8 (n,64); pre_states: cuda int32 (n,8).  Asynchronous
+        on the engine's stream.  Returns the dict of output tensors."""
+        t = self.torch
+        assert blocks.is_cuda and pre_states.is_cuda and blocks.is_contiguous() and pre_states.is_contiguous()
+        assert blocks.dtype == t.uint8 and pre_states.dtype == t.int32
+        n = blocks.numel() // 64
+        assert pre_states.numel() == 8 * n
+        if out is None:
+            out = self.alloc_outputs(n, cursor0)
+        gate, dense, spread, nxt = out["gate"], out["dense"], out["spread"], out["next_states"]
+        rc = self.lib.hsw_witness_blocks(
+            self.h, blocks.data_ptr(), pre_states.data_ptr(), n, cursor0,
+            gate.data_ptr() if gate is not None else None,
+            dense.data_ptr() if dense is not None else None,
+            spread.data_ptr() if spread is not None else None,
+            dense.shape[1] if dense is not None else 0,
+            nxt.data_ptr() if nxt is not None else None, flags)
+        self._ok(rc)
+        return out
+
+    def sha256_chain(self, blocks, n_messages, blocks_per_message, init_states=None):
+        """Plain SHA-256 chain pre-pass: pre-state of every block (lib.rs:188,236)."""
+        t = self.torch
+        pre = t.empty((n_messages * blocks_per_message, 8), dtype=t.int32, device=self.device)
+        rc = self.lib.hsw_sha256_chain(self.h, blocks.data_ptr(), n_messages, blocks_per_message,
+                                       init_states.data_ptr() if init_states is not None else None,
+                                       pre.data_ptr())
+        self._ok(rc)
+        return pre
+
+    def set_timing(self, on=True):
+        self._ok(self.lib.hsw_set_timing(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._ok(self.lib.hsw_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def synchronize(self):
+        self._ok(self.lib.hsw_engine_synchronize(self.h))

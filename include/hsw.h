@@ -1,0 +1,167 @@
+/*
+ * hsw.h -- C ABI of the MI355X SHA-256 witness engine ("halo2 sha witness").
+ *
+ * This is the drop-in boundary for the hot path of zhmolly/halo2-dynamic-sha256:
+ * the reference has NO FFI of its own (it is plain Rust calling halo2-base), so
+ * the boundary is new and sits exactly where `Sha256DynamicConfig::digest`
+ * calls `sha256_compression` once per 64-byte block:
+ *
+ *     reference src/lib.rs:180-189          the block loop (caller)
+ *     reference src/compression.rs:19-25    sha256_compression(ctx, range,
+ *                                           spread_config, bytes[64], pre_state[8])
+ *     reference src/spread.rs:196-233       spread_limb (chip column placement)
+ *
+ * A Rust shim keeps `Sha256DynamicConfig`'s surface, pads/chains on the host,
+ * calls hsw_witness_blocks() once for all blocks of a digest (or a batch of
+ * digests) and replays the returned streams into `Context`/`Region`
+ * (INTEGRATION.md shows the `extern "C"` block).
+ *
+ * Streams (DESIGN.md "Streams"):
+ *   gate cells   per block G cells (hsw_shape.gate_cells_per_block; 66,308 at
+ *                the reference's configuration), in the order the reference
+ *                issues halo2-base gate calls, 4 cells per add/neg/mul_add gate
+ *                and 1 per load_witness.
+ *   chip columns the SpreadConfig advice columns denses[c] / spreads[c]
+ *                (spread.rs:20-21): limb call #n (counted from
+ *                SpreadConfig.num_limb_sum) lands in column n % ncols at row
+ *                n / ncols (spread.rs:202-231).
+ *   next states  8 u32 words per block (compression.rs:197-212).
+ * One cell = 32 bytes = one BN254 scalar-field element, 4 little-endian 64-bit
+ * limbs, canonical (HSW_REPR_CANONICAL) or Montgomery (HSW_REPR_MONTGOMERY,
+ * the in-memory form of halo2curves' Fr) form.
+ *
+ * All entry points return an int status (HSW_OK = 0); nothing unwinds across
+ * the ABI.  Shape violations that the reference would `assert!`/`debug_assert!`
+ * on (lib.rs:57-59,89-90; spread.rs:37; compression.rs:26-27) are hard errors.
+ */
+#ifndef HSW_H
+#define HSW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSW_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define HSW_OK                 0
+#define HSW_ERR_INVALID_ARG    1   /* NULL / misaligned / inconsistent argument */
+#define HSW_ERR_SHAPE          2   /* 16 % num_bits_lookup != 0, ncols == 0, max % 64 != 0 ... */
+#define HSW_ERR_NO_DEVICE      3   /* no usable gfx950 device / HIP runtime */
+#define HSW_ERR_HIP            4   /* a HIP call failed; see hsw_last_error() */
+#define HSW_ERR_UNSUPPORTED    5   /* valid request this build does not implement */
+#define HSW_ERR_TOO_LARGE      6   /* message does not fit max_variable_byte_size (lib.rs:90) */
+#define HSW_ERR_NOMEM          7
+
+/* ---- flags for hsw_witness_blocks ---- */
+#define HSW_REPR_CANONICAL     0u  /* cells hold the canonical integer, LE limbs */
+#define HSW_REPR_MONTGOMERY    1u  /* cells hold x*2^256 mod p (halo2curves Fr memory form) */
+#define HSW_REPR_MASK          1u
+#define HSW_SKIP_GATE          2u  /* do not write the gate stream (d_gate may be NULL) */
+#define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
+
+#define HSW_CELL_BYTES         32u
+
+typedef struct hsw_engine hsw_engine;
+
+/* Shape of the streams for SpreadConfig::configure(num_bits_lookup,
+ * num_advice_columns) (spread.rs:32-74).  All counts are per 64-byte block. */
+typedef struct hsw_shape {
+    uint32_t num_bits_lookup;        /* 16 % it == 0 (spread.rs:37) */
+    uint32_t num_advice_columns;     /* >= 1 */
+    uint32_t limbs_per_spread;       /* 16 / num_bits_lookup (spread.rs:84) */
+    uint32_t cells_per_spread;       /* gate cells of one SpreadConfig::spread call */
+    uint32_t cells_per_state_spread; /* state_to_spread_u32 (compression.rs:215-246) */
+    uint32_t cells_per_sigma;        /* sigma_generic (compression.rs:702-882) */
+    uint32_t cells_per_ch;           /* compression.rs:297-405 */
+    uint32_t cells_per_maj;          /* compression.rs:460-519 */
+    uint32_t cells_per_sched_step;   /* one idx of compression.rs:57-96 */
+    uint32_t cells_per_round;        /* one idx of compression.rs:125-196 */
+    /* offsets (in cells) of the six regions of one block's gate stream */
+    uint32_t off_words;              /* compression.rs:31-47   16 x 16 cells */
+    uint32_t off_msg_spread;         /* compression.rs:53-56   16 state_to_spread_u32 */
+    uint32_t off_sched;              /* compression.rs:57-96   48 steps */
+    uint32_t off_state_spread;       /* compression.rs:109-115 6 state_to_spread_u32 */
+    uint32_t off_rounds;             /* compression.rs:125-196 64 rounds */
+    uint32_t off_feed;               /* compression.rs:197-212 8 x 10 cells */
+    uint32_t gate_cells_per_block;   /* G */
+    uint32_t spread_calls_per_block; /* 2,060 */
+    uint32_t limb_calls_per_block;   /* spread_calls * limbs_per_spread (cursor advance) */
+    uint32_t chip_cells_per_block;   /* 2 * limb_calls_per_block */
+    uint64_t algorithmic_bytes_per_block; /* (G + chip cells) * 32 + 64 + 32 + 32 */
+} hsw_shape;
+
+/* Fill *out for the given SpreadConfig parameters.  Pure host arithmetic. */
+int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out);
+
+/* Number of rows every chip column buffer must hold for n_blocks blocks whose
+ * first limb call is #spread_cursor0: buffer row 0 is absolute chip row
+ * spread_cursor0 / ncols.  Returns 0 on a bad shape. */
+uint64_t hsw_chip_rows(const hsw_shape *shape, uint64_t spread_cursor0, uint64_t n_blocks);
+
+/* Engine bound to one HIP device and stream (hip_stream: a hipStream_t, or
+ * NULL for the device's default stream).  One engine per host thread/stream;
+ * calls on one engine are issued asynchronously in order on that stream. */
+int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
+                      uint32_t num_advice_columns, hsw_engine **out);
+void hsw_engine_destroy(hsw_engine *e);
+int hsw_engine_shape(const hsw_engine *e, hsw_shape *out);
+int hsw_engine_synchronize(hsw_engine *e);
+
+/* Replaces n calls of sha256_compression (compression.rs:19-213).
+ *
+ *   d_blocks      n*64 message bytes            (device memory)
+ *   d_pre_states  n*8 u32 pre-state words       (device memory)
+ *   spread_cursor0  SpreadConfig.num_limb_sum before the first block
+ *                 (spread.rs:26,202); block j starts at cursor0 + j*limb_calls_per_block
+ *   d_gate        n*G cells, 32-byte aligned    (device memory)
+ *   d_chip_dense / d_chip_spread
+ *                 ncols columns each; column c starts at base + c*chip_col_stride
+ *                 cells; hsw_chip_rows() rows are written per column (cells of
+ *                 the first/last row that belong to neighbouring calls are left
+ *                 untouched when the cursor is not a multiple of ncols)
+ *   d_next_states n*8 u32                       (device memory, may be NULL)
+ *   flags         HSW_REPR_* | HSW_SKIP_*
+ *
+ * Asynchronous on the engine's stream. */
+int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d_pre_states,
+                       size_t n_blocks, uint64_t spread_cursor0, void *d_gate,
+                       void *d_chip_dense, void *d_chip_spread, size_t chip_col_stride,
+                       uint32_t *d_next_states, uint32_t flags);
+
+/* Plain SHA-256 chain pre-pass (what makes the blocks of one message
+ * independent; lib.rs:188,236): message m has blocks_per_message consecutive
+ * blocks in d_blocks; its first pre-state is d_init_states[m*8..] (NULL = the
+ * FIPS IV, compression.rs:1003-1012).  Writes the pre-state of every block to
+ * d_pre_states (n_messages*blocks_per_message*8 u32).  Asynchronous. */
+int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
+                     size_t blocks_per_message, const uint32_t *d_init_states,
+                     uint32_t *d_pre_states);
+
+/* Host-pointer convenience: stages inputs H2D, runs hsw_witness_blocks and
+ * copies the requested streams D2H, then synchronizes.  Any output pointer
+ * may be NULL (that stream is then skipped). */
+int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t *pre_states,
+                            size_t n_blocks, uint64_t spread_cursor0, void *gate,
+                            void *chip_dense, void *chip_spread, size_t chip_col_stride,
+                            uint32_t *next_states, uint32_t flags);
+
+/* Duration in milliseconds of the most recent expansion kernel launched by
+ * hsw_witness_blocks on this engine, measured with HIP events recorded on the
+ * engine's stream around that launch.  Synchronizes on the stop event. */
+int hsw_last_kernel_ms(hsw_engine *e, float *ms);
+/* Enable/disable the per-launch event pair (off by default: no overhead). */
+int hsw_set_timing(hsw_engine *e, int enabled);
+
+const char *hsw_strerror(int status);
+/* Detail of the last failure on this engine ("" if none); never NULL. */
+const char *hsw_last_error(const hsw_engine *e);
+uint32_t hsw_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSW_H */

@@ -1,0 +1,44 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hsw():
+    """The product package (directory name has a hyphen -> importlib)."""
+    return importlib.import_module("halo2-dynamic-sha256_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle -- the checker, never the thing under test."""
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def engine_factory(hsw):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    engines = []
+
+    def make(num_bits_lookup=8, num_advice_columns=2):
+        e = hsw.WitnessEngine(0, num_bits_lookup, num_advice_columns)
+        engines.append(e)
+        return e
+
+    yield make
+    for e in engines:
+        e.close()
