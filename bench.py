@@ -49,6 +49,43 @@ def sha_pad_single_block(msgs55):
     return blocks
 
 
+def host_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup cpu quota).
+    A 1-GPU box of the pool exposes every host core in the affinity mask but
+    shares them between tenants (16 per GPU): without a readable quota the
+    count is capped at 16 x visible GPUs.  HSW_BENCH_CORES overrides."""
+    if os.environ.get("HSW_BENCH_CORES"):
+        return max(1, int(os.environ["HSW_BENCH_CORES"]))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota is not None:
+        cores = max(1, min(cores, int(quota)))
+    else:
+        try:
+            import torch
+            ngpu = max(1, torch.cuda.device_count())
+        except Exception:
+            ngpu = 1
+        cores = min(cores, 16 * ngpu)
+    return cores
+
+
 def cpu_baseline(blocks, pre, seconds_target=12.0):
     """Time the CPU oracle (kind 'port': C restatement of the reference's Rust
     path; the Rust crate itself cannot be built offline) on a bounded sample of
@@ -56,11 +93,7 @@ def cpu_baseline(blocks, pre, seconds_target=12.0):
     import threading
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     # calibrate single-thread rate on 8 blocks, streams written (same work as the GPU path)
     o = O.Oracle(8, 2, check=False)
     t0 = time.perf_counter()

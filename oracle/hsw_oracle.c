@@ -105,6 +105,7 @@ struct oracle_ctx {
     uint64_t row_offset;          /* spread.rs:27 */
     int check;
     ofe_t *gate; size_t gate_cap, gate_len;
+    uint8_t *kinds; size_t kinds_cap; int cur_kind;   /* optional per-cell tag stream */
     ofe_t *dense, *spread; size_t col_stride; uint64_t row_base;
     oracle_stats_t st;
     int failed; char msg[256];
@@ -135,6 +136,7 @@ void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap, ofe_t *dens
     c->gate = gate; c->gate_cap = gate_cap; c->gate_len = 0;
     c->dense = dense; c->spread = spread; c->col_stride = col_stride; c->row_base = row_base;
 }
+void oracle_set_kinds(oracle_ctx *c, uint8_t *kinds, size_t cap) { c->kinds = kinds; c->kinds_cap = cap; }
 void oracle_set_cursor(oracle_ctx *c, uint64_t n) {
     c->num_limb_sum = n;
     c->row_offset = n / (uint64_t)c->num_advice_columns;   /* spread.rs:228-231 closed form */
@@ -150,6 +152,8 @@ int oracle_failed(const oracle_ctx *c, const char **msg) {
 /* ------------------------------------------------- halo2-base gate mirror */
 /* One advice cell of the gate stream. */
 static inline void cell(oracle_ctx *c, const ofe_t *v) {
+    if (c->kinds && c->gate_len < c->kinds_cap) c->kinds[c->gate_len] = (uint8_t)c->cur_kind;
+    if (c->cur_kind) c->cur_kind++;       /* 1..4 = position inside a 4-cell gate row */
     if (c->gate) {
         if (c->gate_len < c->gate_cap) c->gate[c->gate_len] = *v;
         else ofail(c, "gate buffer overflow", c->gate_len, c->gate_cap);
@@ -160,6 +164,7 @@ static inline void cell(oracle_ctx *c, const ofe_t *v) {
 /* GateInstructions::load_witness -> [v] */
 static ofe_t g_load_witness(oracle_ctx *c, ofe_t v) {
     c->st.load_witness++;
+    c->cur_kind = 0;
     cell(c, &v);
     return v;
 }
@@ -169,6 +174,7 @@ static ofe_t g_load_zero(oracle_ctx *c) { c->st.load_zero++; return fe_u64(0); }
 static ofe_t g_add(oracle_ctx *c, ofe_t a, ofe_t b) {
     c->st.add++;
     ofe_t one = fe_u64(1), out = fe_add(&a, &b);
+    c->cur_kind = 1;
     cell(c, &a); cell(c, &b); cell(c, &one); cell(c, &out);
     return out;
 }
@@ -176,6 +182,7 @@ static ofe_t g_add(oracle_ctx *c, ofe_t a, ofe_t b) {
 static ofe_t g_neg(oracle_ctx *c, ofe_t a) {
     c->st.neg++;
     ofe_t one = fe_u64(1), zero = fe_u64(0), out = fe_neg(&a);
+    c->cur_kind = 1;
     cell(c, &a); cell(c, &out); cell(c, &one); cell(c, &zero);
     return out;
 }
@@ -183,6 +190,7 @@ static ofe_t g_neg(oracle_ctx *c, ofe_t a) {
 static ofe_t g_mul_add(oracle_ctx *c, ofe_t a, ofe_t b, ofe_t cc) {
     c->st.mul_add++;
     ofe_t ab = fe_mul(&a, &b), out = fe_add(&ab, &cc);
+    c->cur_kind = 1;
     cell(c, &cc); cell(c, &a); cell(c, &b); cell(c, &out);
     return out;
 }

@@ -83,6 +83,12 @@ void oracle_destroy(oracle_ctx *c);
 void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap,
                         ofe_t *dense, ofe_t *spread, size_t col_stride,
                         uint64_t row_base);
+/* Optional tag per gate-stream cell: 0 = load_witness cell, 1..4 = position
+ * inside a 4-cell gate row [x0,x1,x2,x3] whose constraint is x0 + x1*x2 = x3
+ * (add: [a,b,1,out]; neg: [a,-a,1,0]; mul_add: [c,a,b,out]).  This is the
+ * "tape" a placement adaptor needs, and what the gate-equation property test
+ * walks.  Indexed like the gate buffer (reset by oracle_set_outputs). */
+void oracle_set_kinds(oracle_ctx *c, uint8_t *kinds, size_t cap);
 /* Set SpreadConfig.num_limb_sum (row_offset follows: spread.rs:228-231). */
 void oracle_set_cursor(oracle_ctx *c, uint64_t num_limb_sum);
 uint64_t oracle_get_cursor(const oracle_ctx *c);

@@ -53,6 +53,7 @@ def lib():
         L.oracle_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                          C.c_void_p, C.c_size_t, C.c_uint64]
         L.oracle_set_cursor.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_set_kinds.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_get_cursor.restype = C.c_uint64
         L.oracle_get_cursor.argtypes = [C.c_void_p]
         L.oracle_gate_len.restype = C.c_size_t
@@ -182,6 +183,23 @@ class Oracle:
         out.update(digest=dig.tobytes(), blocks=blocks[:nblk], pre_states=pre[:nblk],
                    next_states=nxt[:nblk])
         return out
+
+
+def gate_tape(num_bits_lookup=8, num_advice_columns=2):
+    """Per-cell tags of ONE block's gate stream (input independent): uint8 array
+    of length G, 0 = load_witness cell, 1..4 = position in a gate row whose
+    constraint is x0 + x1*x2 == x3."""
+    G, _ = measure_shape(num_bits_lookup, num_advice_columns)
+    o = Oracle(num_bits_lookup, num_advice_columns, check=True)
+    kinds = np.zeros(G, dtype=np.uint8)
+    o.L.oracle_set_outputs(o.h, None, 0, None, None, 0, 0)
+    o.L.oracle_set_kinds(o.h, kinds.ctypes.data, G)
+    blk = np.arange(64, dtype=np.uint8)
+    nxt = np.zeros(8, dtype=np.uint32)
+    o.L.oracle_sha256_compression(o.h, blk.ctypes.data, INIT_STATE.ctypes.data, nxt.ctypes.data)
+    o.L.oracle_set_kinds(o.h, None, 0)
+    o._check()
+    return kinds
 
 
 def plain_compress(state, block):

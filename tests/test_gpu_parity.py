@@ -74,3 +74,144 @@ def test_batch_64_blocks(engine_factory, oracle):
     blocks, pre = _rand_inputs(64, 4242)
     ref = oracle.Oracle(8, 2, check=True).witness_blocks(blocks, pre)
     _assert_same(_run_gpu(eng, blocks, pre), ref)
+
+
+def test_committed_fingerprints(engine_factory):
+    """HIP path vs the committed golden fixtures (tests/golden/): inputs are
+    rebuilt deterministically, expected hashes come from the JSON file."""
+    import hashlib
+    import json
+    import os
+    from tests.golden.make_golden import golden_inputs
+    fps = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "stream_fingerprints.json")))
+    for case in fps["cases"]:
+        eng = engine_factory(case["num_bits_lookup"], case["num_advice_columns"])
+        blocks, pre = golden_inputs(case["name"])
+        out = _run_gpu(eng, blocks, pre, cursor0=case["cursor0"])
+        assert hashlib.sha256(out["gate"].tobytes()).hexdigest() == case["gate_sha256"], case["name"]
+        assert hashlib.sha256(out["dense"].tobytes()).hexdigest() == case["dense_sha256"], case["name"]
+        assert hashlib.sha256(out["spread"].tobytes()).hexdigest() == case["spread_sha256"], case["name"]
+        assert hashlib.sha256(out["next_states"].tobytes()).hexdigest() == case["next_states_sha256"]
+
+
+def test_chain_kernel_and_16_block_message(engine_factory, oracle):
+    """BASELINE configs[1]: a 1 KiB-class message = 16 chained blocks.  The chain
+    pre-pass must reproduce lib.rs:188,236 (each block's pre-state = previous
+    block's output) and the streams must equal the oracle's digest() run."""
+    import hashlib
+    import torch
+    eng = engine_factory(8, 2)
+    m = bytes(((i * 131 + 7) % 256) for i in range(1015))       # SURVEY 8d C2
+    ref = oracle.Oracle(8, 2, check=True).digest(m, 1024, want_streams=True)
+    assert ref["digest"] == hashlib.sha256(m).digest()
+    tb = torch.from_numpy(ref["blocks"].copy()).cuda()
+    pre = eng.sha256_chain(tb, 1, 16)
+    assert np.array_equal(pre.cpu().numpy().view(np.uint32), ref["pre_states"])
+    out = eng.witness_blocks(tb, pre)
+    eng.synchronize()
+    assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+    assert np.array_equal(out["spread"].cpu().numpy().view(np.uint64), ref["spread"])
+    last = out["next_states"][15].cpu().numpy().view(np.uint32)
+    assert b"".join(int(x).to_bytes(4, "big") for x in last) == ref["digest"]
+
+
+def test_chain_with_custom_init_states(engine_factory, oracle):
+    """Prefix pre-hash (lib.rs:153-160): chains may start from any state."""
+    import torch
+    eng = engine_factory(8, 2)
+    rng = np.random.default_rng(77)
+    nm, bpm = 5, 3
+    blocks = rng.integers(0, 256, (nm * bpm, 64), dtype=np.uint8)
+    init = rng.integers(0, 2**32, (nm, 8), dtype=np.uint64).astype(np.uint32)
+    pre = eng.sha256_chain(torch.from_numpy(blocks).cuda(), nm, bpm,
+                           torch.from_numpy(init.view(np.int32)).cuda()).cpu().numpy().view(np.uint32)
+    for mi in range(nm):
+        st = init[mi].copy()
+        for j in range(bpm):
+            assert np.array_equal(pre[mi * bpm + j], st)
+            st = oracle.plain_compress(st, blocks[mi * bpm + j])
+
+
+def test_skip_flags_leave_buffers_untouched(engine_factory, oracle, hsw):
+    import torch
+    eng = engine_factory(8, 2)
+    blocks, pre = _rand_inputs(2, 31)
+    ref = oracle.Oracle(8, 2).witness_blocks(blocks, pre)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    out = eng.alloc_outputs(2)
+    out["gate"].fill_(-1)
+    out["dense"].fill_(-1)
+    out["spread"].fill_(-1)
+    eng.witness_blocks(tb, tp, out=out, flags=hsw.HSW_SKIP_GATE)
+    eng.synchronize()
+    assert (out["gate"] == -1).all()
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+    out["dense"].fill_(-1)
+    eng.witness_blocks(tb, tp, out=out, flags=hsw.HSW_SKIP_CHIP)
+    eng.synchronize()
+    assert (out["dense"] == -1).all()
+    assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+
+
+def test_cursor_neighbours_preserved(engine_factory, oracle):
+    """With cursor0 % ncols != 0 the first row's earlier columns belong to the
+    previous call and must not be written (spread.rs:202-231)."""
+    import torch
+    eng = engine_factory(8, 3)
+    blocks, pre = _rand_inputs(1, 8)
+    out = eng.alloc_outputs(1, cursor0=2)
+    out["dense"].fill_(-7)
+    out["spread"].fill_(-7)
+    eng.witness_blocks(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                       cursor0=2, out=out)
+    eng.synchronize()
+    d = out["dense"].cpu().numpy()
+    rows = d.shape[1]
+    assert (d[0, 0] == -7).all() and (d[1, 0] == -7).all() and not (d[2, 0] == -7).any()
+    # 2 + 4120 = 4122 limbs = 1374 rows exactly: last row is full
+    assert rows == 1374 and not (d[:, rows - 1] == -7).any()
+
+
+def test_host_pointer_entry(engine_factory, oracle, hsw):
+    """hsw_witness_blocks_host: stages H2D/D2H itself."""
+    eng = engine_factory(8, 2)
+    blocks, pre = _rand_inputs(3, 99)
+    ref = oracle.Oracle(8, 2).witness_blocks(blocks, pre, cursor0=10)
+    G = eng.G
+    rows = eng.chip_rows(10, 3)
+    gate = np.zeros((3 * G, 4), dtype=np.uint64)
+    dense = np.zeros((2, rows, 4), dtype=np.uint64)
+    spread = np.zeros((2, rows, 4), dtype=np.uint64)
+    nxt = np.zeros((3, 8), dtype=np.uint32)
+    rc = eng.lib.hsw_witness_blocks_host(eng.h, blocks.ctypes.data, pre.ctypes.data, 3, 10,
+                                         gate.ctypes.data, dense.ctypes.data, spread.ctypes.data, rows,
+                                         nxt.ctypes.data, 0)
+    assert rc == 0, eng.lib.hsw_last_error(eng.h)
+    assert np.array_equal(gate, ref["gate"]) and np.array_equal(dense, ref["dense"])
+    assert np.array_equal(spread, ref["spread"]) and np.array_equal(nxt, ref["next_states"])
+
+
+def test_argument_errors(engine_factory, hsw):
+    import torch
+    eng = engine_factory(8, 2)
+    N = hsw._native
+    b = torch.zeros((1, 64), dtype=torch.uint8, device="cuda")
+    p = torch.zeros((1, 8), dtype=torch.int32, device="cuda")
+    out = eng.alloc_outputs(1)
+    lib = eng.lib
+    # null inputs
+    assert lib.hsw_witness_blocks(eng.h, None, p.data_ptr(), 1, 0, out["gate"].data_ptr(),
+                                  out["dense"].data_ptr(), out["spread"].data_ptr(), 2060, None, 0) == N.HSW_ERR_INVALID_ARG
+    # stride too small
+    assert lib.hsw_witness_blocks(eng.h, b.data_ptr(), p.data_ptr(), 1, 0, out["gate"].data_ptr(),
+                                  out["dense"].data_ptr(), out["spread"].data_ptr(), 100, None, 0) == N.HSW_ERR_INVALID_ARG
+    # misaligned gate
+    assert lib.hsw_witness_blocks(eng.h, b.data_ptr(), p.data_ptr(), 1, 0, out["gate"].data_ptr() + 8,
+                                  out["dense"].data_ptr(), out["spread"].data_ptr(), 2060, None, 0) == N.HSW_ERR_INVALID_ARG
+    # unknown flags
+    assert lib.hsw_witness_blocks(eng.h, b.data_ptr(), p.data_ptr(), 1, 0, out["gate"].data_ptr(),
+                                  out["dense"].data_ptr(), out["spread"].data_ptr(), 2060, None, 1 << 20) == N.HSW_ERR_INVALID_ARG
+    # zero blocks is a no-op
+    assert lib.hsw_witness_blocks(eng.h, None, None, 0, 0, None, None, None, 0, None, 0) == N.HSW_OK
+    assert b"" != lib.hsw_last_error(eng.h)

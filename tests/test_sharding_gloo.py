@@ -1,0 +1,85 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank produces its contiguous shard
+(the oracle stands in for the HIP kernel here -- this test is about the shard
+plan, cursor arithmetic and the all-gather assembly, not about compute), the
+shards are all-gathered, and every rank must hold exactly the serial streams."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_blocks, bits, ncols, cursor0, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import importlib
+        import torch
+        import torch.distributed as dist
+        from oracle import oracle as O
+        sh = importlib.import_module("halo2-dynamic-sha256_amd.sharding")
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rng = np.random.default_rng(2718)
+        blocks = rng.integers(0, 256, (n_blocks, 64), dtype=np.uint8)
+        pre = rng.integers(0, 2**32, (n_blocks, 8), dtype=np.uint64).astype(np.uint32)
+        G, LC = O.measure_shape(bits, ncols)
+        starts, counts = zip(*[sh.shard_range(n_blocks, world, r) for r in range(world)])
+        s, c = starts[rank], counts[rank]
+        w = O.Oracle(bits, ncols, check=True).witness_blocks(
+            blocks[s:s + c], pre[s:s + c], cursor0=sh.shard_cursor(cursor0, s, LC))
+        gate = sh.allgather_gate(dist, torch.from_numpy(w["gate"].view(np.int64)), counts, G)
+        dense = sh.allgather_chip(dist, torch.from_numpy(w["dense"].view(np.int64)), cursor0, starts,
+                                  counts, LC, ncols)
+        spread = sh.allgather_chip(dist, torch.from_numpy(w["spread"].view(np.int64)), cursor0, starts,
+                                   counts, LC, ncols)
+        serial = O.Oracle(bits, ncols, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
+        ok = (np.array_equal(gate.numpy().view(np.uint64), serial["gate"])
+              and np.array_equal(dense.numpy().view(np.uint64), serial["dense"])
+              and np.array_equal(spread.numpy().view(np.uint64), serial["spread"]))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, ""))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("n_blocks,bits,ncols,cursor0", [(4, 8, 2, 0), (5, 8, 2, 3), (3, 8, 3, 1), (1, 16, 1, 0)])
+def test_two_rank_shards_assemble_to_serial_streams(n_blocks, bits, ncols, cursor0):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_blocks * 7 + ncols) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_blocks, bits, ncols, cursor0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, "rank %d: %s" % (rank, err)
+
+
+def test_shard_plan_arithmetic(hsw):
+    sh = __import__("importlib").import_module("halo2-dynamic-sha256_amd.sharding")
+    # contiguous, complete, remainder first
+    for n, w in [(4096, 8), (65536, 8), (5, 2), (3, 4), (0, 2)]:
+        rs = [sh.shard_range(n, w, r) for r in range(w)]
+        assert rs[0][0] == 0 and sum(c for _, c in rs) == n
+        for (s0, c0), (s1, _) in zip(rs, rs[1:]):
+            assert s0 + c0 == s1
+        assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
+    # BASELINE configs[3]: 65,536 messages over 8 GPUs -> 8,192 each, rows line up
+    s, c = sh.shard_range(65536, 8, 3)
+    assert (s, c) == (3 * 8192, 8192)
+    assert sh.shard_cursor(0, s, 4120) == 3 * 8192 * 4120
+    assert sh.shard_row_window(0, s, c, 4120, 2) == (3 * 8192 * 2060, 8192 * 2060)
+    # the C ABI's row count agrees with the python plan
+    import ctypes as C
+    shp = hsw.shape_query(8, 3)
+    for cur, st, nb in [(0, 0, 1), (1, 2, 3), (2, 5, 4)]:
+        cabs = sh.shard_cursor(cur, st, 4120)
+        assert sh.shard_row_window(cur, st, nb, 4120, 3)[1] == hsw._native.lib().hsw_chip_rows(C.byref(shp), cabs, nb)
