@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsw.so")
+LIB_PATH = os.environ.get("HSW_LIB_OVERRIDE") or os.path.join(_HERE, "libhsw.so")   # override: A/B tuning only
 CSRC = os.path.join(_HERE, "csrc")
 
 HSW_OK = 0
@@ -45,7 +45,7 @@ SYMBOLS = (
     "hsw_shape_query", "hsw_chip_rows", "hsw_engine_create", "hsw_engine_destroy",
     "hsw_engine_shape", "hsw_engine_synchronize", "hsw_witness_blocks", "hsw_sha256_chain",
     "hsw_witness_blocks_host", "hsw_last_kernel_ms", "hsw_set_timing", "hsw_strerror",
-    "hsw_last_error", "hsw_abi_version",
+    "hsw_last_error", "hsw_abi_version", "hsw_engine_set_option", "hsw_fill_calibrate",
 )
 
 
@@ -99,6 +99,12 @@ def lib():
                                           C.c_size_t, u32p, C.c_uint32]
     L.hsw_last_kernel_ms.restype = C.c_int
     L.hsw_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if hasattr(L, "hsw_engine_set_option"):   # absent only in pre-ABI-1 A/B builds
+        L.hsw_engine_set_option.restype = C.c_int
+        L.hsw_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    if hasattr(L, "hsw_fill_calibrate"):
+        L.hsw_fill_calibrate.restype = C.c_int
+        L.hsw_fill_calibrate.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_float)]
     L.hsw_set_timing.restype = C.c_int
     L.hsw_set_timing.argtypes = [vp, C.c_int]
     _lib = L

@@ -20,6 +20,8 @@ struct hsw_engine {
     hipStream_t stream = nullptr;
     hsw_shape shape{};
     int limbs = 2;
+    int parts = 0;             // waves per block; 0 = choose from the batch size
+    int tile = 32;             // tile width in cells: 32, 64 or 128
     bool timing = false;
     bool timed = false;        // ev0/ev1 bracket a launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -63,6 +65,18 @@ int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSucc
         e->err = buf;
     }
     return status;
+}
+
+// Waves per block.  A block is 64 + 48 + ... independent units; one wave can
+// expand all of them (lane = unit), or the units can be dealt to 2..16 waves.
+// Large batches fill the chip with one wave per block; small ones (e.g. the
+// 16-block message of BASELINE configs[1]) need the split to occupy 256 CUs.
+int choose_parts(const hsw_engine *e, size_t n_blocks) {
+    const int min_parts = e->tile / 32;           // a T-cell tile has 64*32/T rows
+    if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
+    int parts = min_parts;
+    while (parts < 16 && n_blocks * (size_t)parts < 2048) parts *= 2;
+    return parts;
 }
 
 // Makes the engine's device current for the scope of one call.
@@ -177,6 +191,23 @@ int hsw_engine_synchronize(hsw_engine *e) {
     return HSW_OK;
 }
 
+int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
+    if (!e || !name) return HSW_ERR_INVALID_ARG;
+    if (std::strcmp(name, "parts") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return set_err(e, HSW_ERR_INVALID_ARG, "parts must be 0 (auto), 1, 2, 4, 8 or 16");
+        e->parts = (int)value;
+        return HSW_OK;
+    }
+    if (std::strcmp(name, "tile") == 0) {
+        if (value != 32 && value != 64 && value != 128)
+            return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 32, 64 or 128");
+        e->tile = (int)value;
+        return HSW_OK;
+    }
+    return set_err(e, HSW_ERR_INVALID_ARG, "unknown option");
+}
+
 int hsw_set_timing(hsw_engine *e, int enabled) {
     if (!e) return HSW_ERR_INVALID_ARG;
     e->timing = enabled != 0;
@@ -247,6 +278,7 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         p.cursor0 = spread_cursor0;
         p.ncols = e->shape.num_advice_columns;
         p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP);
+        p.parts = (uint32_t)choose_parts(e, n_blocks);
         if (done != 0) {
             // later chunks: keep buffer row 0 fixed by pre-offsetting the column
             // base instead of the cursor origin
@@ -259,7 +291,7 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
                 p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES;
             }
         }
-        he = hsw::launch_expand(p, e->limbs, e->stream);
+        he = hsw::launch_expand(p, e->limbs, e->tile, e->stream);
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_expand_kernel", he);
     }
     if (e->timing) {
@@ -267,6 +299,20 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
         e->timed = true;
     }
+    return HSW_OK;
+}
+
+int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms) {
+    if (!e || !d_buf || !ms || ((uintptr_t)d_buf & 15u)) return HSW_ERR_INVALID_ARG;
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipError_t he = hipEventRecord(e->ev0, e->stream);
+    if (he == hipSuccess) he = hsw::launch_fill(d_buf, bytes, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(e->ev1, e->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e->ev1);
+    if (he == hipSuccess) he = hipEventElapsedTime(ms, e->ev0, e->ev1);
+    e->timed = false;
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_fill_calibrate", he);
     return HSW_OK;
 }
 

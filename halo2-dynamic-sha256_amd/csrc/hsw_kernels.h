@@ -27,13 +27,18 @@ struct ExpandParams {
     uint64_t cursor0;             // SpreadConfig.num_limb_sum before block 0
     uint32_t ncols;               // num_advice_columns
     uint32_t flags;               // HSW_K_*
+    uint32_t parts;               // waves per block: 1, 2, 4, 8 or 16
 };
 
 // limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count
 // this build has no instantiation for.
-hipError_t launch_expand(const ExpandParams &p, int limbs, hipStream_t stream);
+// tile = cells per tile row: 32 (64 units per wave), 64 (32 units, parts >= 2) or
+// 128 (16 units, parts >= 4).
+hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t stream);
 hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_per_message,
                         const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
+
+hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 
 }  // namespace hsw
 #endif

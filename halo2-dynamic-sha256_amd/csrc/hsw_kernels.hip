@@ -92,18 +92,22 @@ DEV u32 even_bits(u32 x) {
 // ------------------------------------------------------------------ emitter
 // Per-lane emission state.  Everything except `row`, `active` and `call` is
 // wave-uniform and, after inlining, a compile-time constant at every use.
-template <int T>
+template <int T, int R = 64>
 struct Em {
+    static constexpr int ROWS = R;
     u64 *row;          // this lane's tile row (LDS)
     const u64 *tile;   // tile base (LDS)
     u16 *d16;          // staged dense inputs of spread() calls (LDS)
     uint4 *out;        // this block's gate stream, in 16-byte pieces
     u32 pos;           // cells currently in the tile
-    u32 negmask;       // tile positions that hold a field negation (-x)
+    u64 neg0, neg1;    // tile positions (0..63 / 64..127) that hold a field negation (-x)
     u32 nrows;         // units (rows) of the current phase
     u32 unit_cells;    // gate cells per unit
     u32 cell_base;     // cell index (in block) of unit 0, tile column 0
-    u32 call;          // this lane's next spread-call slot (index into d16)
+    u32 call;          // this lane's next spread-call slot (index into d16, phase-local)
+    u32 unit;          // the unit (word / schedule step / round ...) this lane expands
+    u32 call_first;    // block-relative index of the phase-part's first spread call
+    u32 calls;         // spread calls staged by this phase-part (nrows * calls_per_unit)
     bool active;       // lane < nrows
     bool write_gate;   // HSW_SKIP_GATE not set
 };
@@ -112,8 +116,8 @@ struct Em {
 // [cell_base + r*unit_cells, +ncells).  Lane pairs cover one 32-byte cell
 // (low / high 16 bytes), so a wave-wide store instruction writes 1 KiB
 // contiguous when ncells*2 >= 64.
-template <int T>
-DEV void flush_tile(Em<T> &em, u32 ncells) {
+template <int T, int R>
+DEV void flush_tile(Em<T, R> &em, u32 ncells) {
     __syncthreads();
     if (em.write_gate) {
         const u32 lane = threadIdx.x;
@@ -131,8 +135,9 @@ DEV void flush_tile(Em<T> &em, u32 ncells) {
             o.y = h ? 0u : hi;
             o.z = 0u;
             o.w = 0u;
-            if (em.negmask != 0u) {
-                if (((em.negmask >> p) & 1u) && v != 0ull) {
+            if ((em.neg0 | em.neg1) != 0ull) {    // compile-time after inlining: most tiles hold no neg cell
+                const u64 mword = (T > 64 && p >= 64u) ? em.neg1 : em.neg0;
+                if (((mword >> (p & 63u)) & 1ull) && v != 0ull) {
                     // cell holds p - x (neg gate, compression.rs:320-321), x < 2^31
                     o.x = h ? HSW_P4 : (HSW_P0 - lo);
                     o.y = h ? HSW_P5 : HSW_P1;
@@ -146,68 +151,143 @@ DEV void flush_tile(Em<T> &em, u32 ncells) {
     __syncthreads();
     em.cell_base += ncells;
     em.pos = 0;
-    em.negmask = 0;
+    em.neg0 = 0;
+    em.neg1 = 0;
 }
 
-template <int T>
-DEV void emit(Em<T> &em, u64 v) {
+template <int T, int R>
+DEV void emit(Em<T, R> &em, u64 v) {
     em.row[em.pos] = v;
-    if (++em.pos == (u32)T) flush_tile<T>(em, T);
+    if (++em.pos == (u32)T) flush_tile<T, R>(em, T);
 }
 // cell whose field value is -x (x small): stored as x plus a tile-position flag
-template <int T>
-DEV void emit_neg(Em<T> &em, u64 x) {
-    em.negmask |= 1u << em.pos;
-    emit<T>(em, x);
+template <int T, int R>
+DEV void emit_neg(Em<T, R> &em, u64 x) {
+    if (em.pos < 64u) em.neg0 |= 1ull << em.pos;
+    else em.neg1 |= 1ull << (em.pos - 64u);
+    emit<T, R>(em, x);
 }
 
-template <int T>
-DEV void phase_begin(Em<T> &em, u32 nrows, u32 unit_cells, u32 cell_base, u32 call_base,
-                     u32 calls_per_unit) {
+// Unit expanded by this lane in a phase of n_units units split over `parts` waves
+// (same rule as phase_begin; idle lanes shadow the last active one).
+DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
     const u32 lane = threadIdx.x;
+    u32 nrows, unit_lo;
+    if (n_units % parts == 0) { nrows = n_units / parts; unit_lo = part * nrows; }
+    else { nrows = part == 0 ? n_units : 0; unit_lo = 0; }
+    return unit_lo + (lane < nrows ? lane : (nrows ? nrows - 1 : 0));
+}
+
+// A phase is `n_units` independent units of `unit_cells` gate cells each.  With
+// the block split over `parts` waves, part k expands units [k*n/parts, (k+1)*n/parts)
+// (phases whose unit count is not a multiple of `parts` run on part 0 alone).
+// Returns false if this wave has nothing to do in the phase (wave-uniform).
+template <int T, int R>
+DEV bool phase_begin(Em<T, R> &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
+                     u32 call_base, u32 calls_per_unit) {
+    const u32 lane = threadIdx.x;
+    u32 nrows, unit_lo;
+    if (n_units % parts == 0) {
+        nrows = n_units / parts;
+        unit_lo = part * nrows;
+    } else {
+        nrows = part == 0 ? n_units : 0;
+        unit_lo = 0;
+    }
     em.nrows = nrows;
     em.unit_cells = unit_cells;
-    em.cell_base = cell_base;
+    em.cell_base = phase_off + unit_lo * unit_cells;
     em.pos = 0;
-    em.negmask = 0;
+    em.neg0 = 0;
+    em.neg1 = 0;
     em.active = lane < nrows;
-    em.call = call_base + (lane < nrows ? lane : nrows - 1) * calls_per_unit;
+    const u32 r = lane < nrows ? lane : (nrows ? nrows - 1 : 0);
+    em.unit = unit_lo + r;
+    em.call = r * calls_per_unit;
+    em.call_first = call_base + unit_lo * calls_per_unit;
+    em.calls = nrows * calls_per_unit;
+    return nrows != 0;
 }
-template <int T>
-DEV void phase_end(Em<T> &em) {
-    if (em.pos != 0) flush_tile<T>(em, em.pos);
+
+// Chip columns of the spread calls staged by this phase-part (spread.rs:196-233):
+// limb call n (absolute, counted from SpreadConfig.num_limb_sum = 0) lands in
+// column n % ncols at row n / ncols; buffer row 0 = row cursor0 / ncols.  Every
+// column receives one contiguous run of rows.
+template <int L, int T, int R>
+DEV void flush_chip(const Em<T, R> &em, const ExpandParams &p, u64 block_first_limb) {
+    constexpr int B = 16 / L;
+    constexpr u32 MASK = (1u << B) - 1u;
+    if (em.calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
+    __syncthreads();                                                   // d16 staged by all lanes
+    const u32 lane = threadIdx.x;
+    const u64 ncols = p.ncols;
+    const u64 first = block_first_limb + (u64)em.call_first * L;       // first limb call of this run
+    const u64 last = first + (u64)em.calls * L - 1;
+    const u64 row0 = p.cursor0 / ncols;
+    uint4 *cd = reinterpret_cast<uint4 *>(p.chip_dense);
+    uint4 *cs = reinterpret_cast<uint4 *>(p.chip_spread);
+    for (u64 c = 0; c < ncols; c++) {
+        if (last < c) continue;
+        const u64 row_lo = (first + ncols - 1 - c) / ncols;            // first row with row*ncols + c >= first
+        const u64 row_hi = (last - c) / ncols;                         // last row with row*ncols + c <= last
+        if (row_hi < row_lo) continue;
+        const u32 count = (u32)(row_hi - row_lo + 1);
+        const u32 n0 = (u32)(row_lo * ncols + c - first);              // run-relative limb index of row_lo
+        const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
+        for (u32 i = lane; i < 2u * count; i += 64) {
+            const u32 k = i >> 1, hpart = i & 1u;
+            const u32 n = n0 + k * (u32)ncols;
+            const u32 call = n / L, j = n % L;
+            const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+            uint4 od, os;
+            od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
+            os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
+            cd[base + i] = od;
+            cs[base + i] = os;
+        }
+    }
+    __syncthreads();
+}
+
+template <int L, int T, int R>
+DEV void phase_end(Em<T, R> &em, const ExpandParams &p, u64 block_first_limb) {
+    if (em.pos != 0) flush_tile<T, R>(em, em.pos);
+    flush_chip<L, T, R>(em, p, block_first_limb);
 }
 
 // ---------------------------------------------------- halo2-base gate cells
 // (cell orders: DESIGN.md assumption A1)
-template <int T> DEV void g_lw(Em<T> &em, u64 v) { emit<T>(em, v); }                 // [v]
-template <int T> DEV u64 g_add(Em<T> &em, u64 a, u64 b) {                            // [a, b, 1, a+b]
+template <int T, int R>
+DEV void g_lw(Em<T, R> &em, u64 v) { emit<T, R>(em, v); }                 // [v]
+template <int T, int R>
+DEV u64 g_add(Em<T, R> &em, u64 a, u64 b) {                            // [a, b, 1, a+b]
     const u64 r = a + b;
-    emit<T>(em, a); emit<T>(em, b); emit<T>(em, 1); emit<T>(em, r);
+    emit<T, R>(em, a); emit<T, R>(em, b); emit<T, R>(em, 1); emit<T, R>(em, r);
     return r;
 }
 // mul_add(a, b, c) = a*b + c -> [c, a, b, out]; `out` is passed in (computed by
 // shifts by the caller: every b is a power of two or a 3-term sum of them).
-template <int T> DEV void g_mul_add(Em<T> &em, u64 a, u64 b, u64 c, u64 out) {
-    emit<T>(em, c); emit<T>(em, a); emit<T>(em, b); emit<T>(em, out);
+template <int T, int R>
+DEV void g_mul_add(Em<T, R> &em, u64 a, u64 b, u64 c, u64 out) {
+    emit<T, R>(em, c); emit<T, R>(em, a); emit<T, R>(em, b); emit<T, R>(em, out);
 }
 
 // ------------------------------------------------------- spread.rs mirrors
 // SpreadConfig::spread (spread.rs:76-123) on a 16-bit dense value.
-template <int L, int T>
-DEV u32 sc_spread(Em<T> &em, u32 dense) {
+template <int L, int T, int R>
+DEV u32 sc_spread(Em<T, R> &em, u32 dense) {
     constexpr int B = 16 / L;
     constexpr u32 MASK = (1u << B) - 1u;
     if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced in the chip pass
     em.call++;
 #pragma unroll
-    for (int j = 0; j < L; j++) g_lw<T>(em, (dense >> (B * j)) & MASK);              // :86-88
+    for (int j = 0; j < L; j++) g_lw<T, R>(em, (dense >> (B * j)) & MASK);              // :86-88
     u32 sum = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {                                                    // :91-98
         const u32 limb = (dense >> (B * j)) & MASK;
         const u32 ns = sum | (limb << (B * j));
-        g_mul_add<T>(em, limb, 1u << (B * j), sum, ns);
+        g_mul_add<T, R>(em, limb, 1u << (B * j), sum, ns);
         sum = ns;
     }
     u32 acc = 0;
@@ -215,41 +295,41 @@ DEV u32 sc_spread(Em<T> &em, u32 dense) {
     for (int j = 0; j < L; j++) {                                                    // :112-121
         const u32 limb = (dense >> (B * j)) & MASK;
         const u32 sl = spread16(limb);
-        g_lw<T>(em, sl);                                                             // spread_limb :225
+        g_lw<T, R>(em, sl);                                                             // spread_limb :225
         const u32 na = acc | (sl << (2 * B * j));
-        g_mul_add<T>(em, sl, (u64)1 << (2 * B * j), acc, na);
+        g_mul_add<T, R>(em, sl, (u64)1 << (2 * B * j), acc, na);
         acc = na;
     }
     return acc;
 }
 
 // state_to_spread_u32 (compression.rs:215-246)
-template <int L, int T>
-DEV void state_to_spread(Em<T> &em, u32 x) {
+template <int L, int T, int R>
+DEV void state_to_spread(Em<T, R> &em, u32 x) {
     const u32 lo = x & 0xffffu, hi = x >> 16;
-    g_lw<T>(em, lo);                                     // :230
-    g_lw<T>(em, hi);                                     // :231
-    g_mul_add<T>(em, hi, 1u << 16, lo, x);               // :232-237
-    sc_spread<L, T>(em, lo);                             // :243
-    sc_spread<L, T>(em, hi);                             // :244
+    g_lw<T, R>(em, lo);                                     // :230
+    g_lw<T, R>(em, hi);                                     // :231
+    g_mul_add<T, R>(em, hi, 1u << 16, lo, x);               // :232-237
+    sc_spread<L, T, R>(em, lo);                             // :243
+    sc_spread<L, T, R>(em, hi);                             // :244
 }
 
 // mod_u32 (compression.rs:266-295); x < 2^35
-template <int T>
-DEV u32 mod_u32(Em<T> &em, u64 x) {
+template <int T, int R>
+DEV u32 mod_u32(Em<T, R> &em, u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    g_lw<T>(em, lo);                                     // :280
-    g_lw<T>(em, hi);                                     // :281
-    g_mul_add<T>(em, hi, (u64)1 << 32, lo, x);           // :283-288
+    g_lw<T, R>(em, lo);                                     // :280
+    g_lw<T, R>(em, hi);                                     // :281
+    g_mul_add<T, R>(em, hi, (u64)1 << 32, lo, x);           // :283-288
     return lo;
 }
 
 // { spread(even); spread(odd); 2*odd_spread + even_spread } (compression.rs:344-354 etc.)
-template <int L, int T>
-DEV void recheck_even_odd(Em<T> &em, u32 even, u32 odd) {
-    const u32 es = sc_spread<L, T>(em, even);
-    const u32 os = sc_spread<L, T>(em, odd);
-    g_mul_add<T>(em, 2, os, es, (u64)es + 2ull * (u64)os);
+template <int L, int T, int R>
+DEV void recheck_even_odd(Em<T, R> &em, u32 even, u32 odd) {
+    const u32 es = sc_spread<L, T, R>(em, even);
+    const u32 os = sc_spread<L, T, R>(em, odd);
+    g_mul_add<T, R>(em, 2, os, es, (u64)es + 2ull * (u64)os);
 }
 
 // sigma_generic (compression.rs:702-882).  S1..S3 are STARTS[1..3]; SHa/SHb/SHc
@@ -284,116 +364,125 @@ struct SigmaLower1 {   // :681-689
     static constexpr u64 C3 = (1ull << 18) + (1ull << 4) + (1ull << 0);
 };
 
-template <class SG, int L, int T>
-DEV u32 sigma_generic(Em<T> &em, u32 x) {
+template <class SG, int L, int T, int R>
+DEV u32 sigma_generic(Em<T, R> &em, u32 x) {
     const u64 X = spread32(x);                               // x_spread.1 * 2^32 + x_spread.0
     // :719-734 the four pieces, spread bits [2*start, 2*end) shifted to 0
     const u64 pa = X & ((1ull << (2 * SG::S1)) - 1);
     const u64 pb = (X >> (2 * SG::S1)) & ((1ull << (2 * (SG::S2 - SG::S1))) - 1);
     const u64 pc = (X >> (2 * SG::S2)) & ((1ull << (2 * (SG::S3 - SG::S2))) - 1);
     const u64 pd = X >> (2 * SG::S3);
-    g_lw<T>(em, pa); g_lw<T>(em, pb); g_lw<T>(em, pc); g_lw<T>(em, pd);
+    g_lw<T, R>(em, pa); g_lw<T, R>(em, pb); g_lw<T, R>(em, pc); g_lw<T, R>(em, pd);
     // :736-754 recomposition
     u64 sum = pa, ns;
-    ns = sum + (pb << (2 * SG::S1)); g_mul_add<T>(em, pb, 1ull << (2 * SG::S1), sum, ns); sum = ns;
-    ns = sum + (pc << (2 * SG::S2)); g_mul_add<T>(em, pc, 1ull << (2 * SG::S2), sum, ns); sum = ns;
-    ns = sum + (pd << (2 * SG::S3)); g_mul_add<T>(em, pd, 1ull << (2 * SG::S3), sum, ns); sum = ns;
+    ns = sum + (pb << (2 * SG::S1)); g_mul_add<T, R>(em, pb, 1ull << (2 * SG::S1), sum, ns); sum = ns;
+    ns = sum + (pc << (2 * SG::S2)); g_mul_add<T, R>(em, pc, 1ull << (2 * SG::S2), sum, ns); sum = ns;
+    ns = sum + (pd << (2 * SG::S3)); g_mul_add<T, R>(em, pd, 1ull << (2 * SG::S3), sum, ns); sum = ns;
     // :755-760 x_composed
-    g_mul_add<T>(em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
+    g_mul_add<T, R>(em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
     // :780-808 r_spread = sum coeff_i * piece_i  (< 2^64 by construction)
     u64 r = 0, nr;
-    nr = r + SG::C0 * pa; g_mul_add<T>(em, SG::C0, pa, r, nr); r = nr;
-    nr = r + SG::C1 * pb; g_mul_add<T>(em, SG::C1, pb, r, nr); r = nr;
-    nr = r + SG::C2 * pc; g_mul_add<T>(em, SG::C2, pc, r, nr); r = nr;
-    nr = r + SG::C3 * pd; g_mul_add<T>(em, SG::C3, pd, r, nr); r = nr;
+    nr = r + SG::C0 * pa; g_mul_add<T, R>(em, SG::C0, pa, r, nr); r = nr;
+    nr = r + SG::C1 * pb; g_mul_add<T, R>(em, SG::C1, pb, r, nr); r = nr;
+    nr = r + SG::C2 * pc; g_mul_add<T, R>(em, SG::C2, pc, r, nr); r = nr;
+    nr = r + SG::C3 * pd; g_mul_add<T, R>(em, SG::C3, pd, r, nr); r = nr;
     // :811-836
     const u32 r_lo = (u32)r, r_hi = (u32)(r >> 32);
-    g_lw<T>(em, r_lo); g_lw<T>(em, r_hi);
-    g_mul_add<T>(em, r_hi, 1ull << 32, r_lo, r);
+    g_lw<T, R>(em, r_lo); g_lw<T, R>(em, r_hi);
+    g_mul_add<T, R>(em, r_hi, 1ull << 32, r_lo, r);
     // :843-846
     const u32 lo_even = even_bits(r_lo), lo_odd = even_bits(r_lo >> 1);
     const u32 hi_even = even_bits(r_hi), hi_odd = even_bits(r_hi >> 1);
-    g_lw<T>(em, lo_even); g_lw<T>(em, lo_odd);
-    g_lw<T>(em, hi_even); g_lw<T>(em, hi_odd);
-    recheck_even_odd<L, T>(em, lo_even, lo_odd);             // :852-862
-    recheck_even_odd<L, T>(em, hi_even, hi_odd);             // :863-873
+    g_lw<T, R>(em, lo_even); g_lw<T, R>(em, lo_odd);
+    g_lw<T, R>(em, hi_even); g_lw<T, R>(em, hi_odd);
+    recheck_even_odd<L, T, R>(em, lo_even, lo_odd);             // :852-862
+    recheck_even_odd<L, T, R>(em, hi_even, hi_odd);             // :863-873
     const u32 out = (hi_even << 16) | lo_even;
-    g_mul_add<T>(em, hi_even, 1u << 16, lo_even, out);       // :874-879
+    g_mul_add<T, R>(em, hi_even, 1u << 16, lo_even, out);       // :874-879
     return out;
 }
 
 // ch (compression.rs:297-405); x, y, z are the dense words e, f, g
-template <int L, int T>
-DEV u32 ch_gadget(Em<T> &em, u32 x, u32 y, u32 z) {
+template <int L, int T, int R>
+DEV u32 ch_gadget(Em<T, R> &em, u32 x, u32 y, u32 z) {
     const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
     const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
     const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
     const u32 MASK_EVEN_32 = 0x55555555u;
-    const u32 p_lo = (u32)g_add<T>(em, x_lo, y_lo);          // :309-313
-    const u32 p_hi = (u32)g_add<T>(em, x_hi, y_hi);          // :314-318
+    const u32 p_lo = (u32)g_add<T, R>(em, x_lo, y_lo);          // :309-313
+    const u32 p_hi = (u32)g_add<T, R>(em, x_hi, y_hi);          // :314-318
     // neg: [a, -a, 1, 0]                                       :320-321
-    emit<T>(em, x_lo); emit_neg<T>(em, x_lo); emit<T>(em, 1); emit<T>(em, 0);
-    emit<T>(em, x_hi); emit_neg<T>(em, x_hi); emit<T>(em, 1); emit<T>(em, 0);
+    emit<T, R>(em, x_lo); emit_neg<T, R>(em, x_lo); emit<T, R>(em, 1); emit<T, R>(em, 0);
+    emit<T, R>(em, x_hi); emit_neg<T, R>(em, x_hi); emit<T, R>(em, 1); emit<T, R>(em, 0);
     // three_add(Constant(MASK), -x, z)                         :322-335, :521-530
     const u32 t_lo = MASK_EVEN_32 - x_lo;
-    emit<T>(em, MASK_EVEN_32); emit_neg<T>(em, x_lo); emit<T>(em, 1); emit<T>(em, t_lo);
-    const u32 q_lo = (u32)g_add<T>(em, t_lo, z_lo);
+    emit<T, R>(em, MASK_EVEN_32); emit_neg<T, R>(em, x_lo); emit<T, R>(em, 1); emit<T, R>(em, t_lo);
+    const u32 q_lo = (u32)g_add<T, R>(em, t_lo, z_lo);
     const u32 t_hi = MASK_EVEN_32 - x_hi;
-    emit<T>(em, MASK_EVEN_32); emit_neg<T>(em, x_hi); emit<T>(em, 1); emit<T>(em, t_hi);
-    const u32 q_hi = (u32)g_add<T>(em, t_hi, z_hi);
+    emit<T, R>(em, MASK_EVEN_32); emit_neg<T, R>(em, x_hi); emit<T, R>(em, 1); emit<T, R>(em, t_hi);
+    const u32 q_hi = (u32)g_add<T, R>(em, t_hi, z_hi);
     // :336-343 four even/odd splits before any re-check
     const u32 p_lo_even = even_bits(p_lo), p_lo_odd = even_bits(p_lo >> 1);
     const u32 p_hi_even = even_bits(p_hi), p_hi_odd = even_bits(p_hi >> 1);
     const u32 q_lo_even = even_bits(q_lo), q_lo_odd = even_bits(q_lo >> 1);
     const u32 q_hi_even = even_bits(q_hi), q_hi_odd = even_bits(q_hi >> 1);
-    g_lw<T>(em, p_lo_even); g_lw<T>(em, p_lo_odd);
-    g_lw<T>(em, p_hi_even); g_lw<T>(em, p_hi_odd);
-    g_lw<T>(em, q_lo_even); g_lw<T>(em, q_lo_odd);
-    g_lw<T>(em, q_hi_even); g_lw<T>(em, q_hi_odd);
-    recheck_even_odd<L, T>(em, p_lo_even, p_lo_odd);         // :344-354
-    recheck_even_odd<L, T>(em, p_hi_even, p_hi_odd);         // :355-365
-    recheck_even_odd<L, T>(em, q_lo_even, q_lo_odd);         // :366-376
-    recheck_even_odd<L, T>(em, q_hi_even, q_hi_odd);         // :377-387
-    const u32 out_lo = (u32)g_add<T>(em, p_lo_odd, q_lo_odd);    // :388-392
-    const u32 out_hi = (u32)g_add<T>(em, p_hi_odd, q_hi_odd);    // :393-397
+    g_lw<T, R>(em, p_lo_even); g_lw<T, R>(em, p_lo_odd);
+    g_lw<T, R>(em, p_hi_even); g_lw<T, R>(em, p_hi_odd);
+    g_lw<T, R>(em, q_lo_even); g_lw<T, R>(em, q_lo_odd);
+    g_lw<T, R>(em, q_hi_even); g_lw<T, R>(em, q_hi_odd);
+    recheck_even_odd<L, T, R>(em, p_lo_even, p_lo_odd);         // :344-354
+    recheck_even_odd<L, T, R>(em, p_hi_even, p_hi_odd);         // :355-365
+    recheck_even_odd<L, T, R>(em, q_lo_even, q_lo_odd);         // :366-376
+    recheck_even_odd<L, T, R>(em, q_hi_even, q_hi_odd);         // :377-387
+    const u32 out_lo = (u32)g_add<T, R>(em, p_lo_odd, q_lo_odd);    // :388-392
+    const u32 out_hi = (u32)g_add<T, R>(em, p_hi_odd, q_hi_odd);    // :393-397
     const u32 out = (out_hi << 16) + out_lo;
-    g_mul_add<T>(em, out_hi, 1u << 16, out_lo, out);         // :398-403
+    g_mul_add<T, R>(em, out_hi, 1u << 16, out_lo, out);         // :398-403
     return out;
 }
 
 // maj (compression.rs:460-519)
-template <int L, int T>
-DEV u32 maj_gadget(Em<T> &em, u32 x, u32 y, u32 z) {
+template <int L, int T, int R>
+DEV u32 maj_gadget(Em<T, R> &em, u32 x, u32 y, u32 z) {
     const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
     const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
     const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
-    u64 t = g_add<T>(em, x_lo, y_lo);
-    const u32 m_lo = (u32)g_add<T>(em, t, z_lo);             // :472-478
-    t = g_add<T>(em, x_hi, y_hi);
-    const u32 m_hi = (u32)g_add<T>(em, t, z_hi);             // :479-485
+    u64 t = g_add<T, R>(em, x_lo, y_lo);
+    const u32 m_lo = (u32)g_add<T, R>(em, t, z_lo);             // :472-478
+    t = g_add<T, R>(em, x_hi, y_hi);
+    const u32 m_hi = (u32)g_add<T, R>(em, t, z_hi);             // :479-485
     const u32 m_lo_even = even_bits(m_lo), m_lo_odd = even_bits(m_lo >> 1);
     const u32 m_hi_even = even_bits(m_hi), m_hi_odd = even_bits(m_hi >> 1);
-    g_lw<T>(em, m_lo_even); g_lw<T>(em, m_lo_odd);           // :486-487
-    g_lw<T>(em, m_hi_even); g_lw<T>(em, m_hi_odd);           // :488-489
-    recheck_even_odd<L, T>(em, m_lo_even, m_lo_odd);         // :490-500
-    recheck_even_odd<L, T>(em, m_hi_even, m_hi_odd);         // :501-511
+    g_lw<T, R>(em, m_lo_even); g_lw<T, R>(em, m_lo_odd);           // :486-487
+    g_lw<T, R>(em, m_hi_even); g_lw<T, R>(em, m_hi_odd);           // :488-489
+    recheck_even_odd<L, T, R>(em, m_lo_even, m_lo_odd);         // :490-500
+    recheck_even_odd<L, T, R>(em, m_hi_even, m_hi_odd);         // :501-511
     const u32 out = (m_hi_odd << 16) | m_lo_odd;
-    g_mul_add<T>(em, m_hi_odd, 1u << 16, m_lo_odd, out);     // :512-517
+    g_mul_add<T, R>(em, m_hi_odd, 1u << 16, m_lo_odd, out);     // :512-517
     return out;
 }
 
 // --------------------------------------------------------------- the kernel
-template <int L, int T>
+// T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
+// units one wave expands per phase; a block needs parts >= 64/R waves.
+template <int L, int T, int R>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     using LY = Lay<L>;
-    __shared__ u64 s_tile[64 * (T + 1)];
-    __shared__ u32 sW[64];
-    __shared__ u32 sA[68];     // sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
-    __shared__ u32 sE[68];     // sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
-    __shared__ u16 s_d16[(LY::SPREAD_CALLS + 3) & ~3];
+    static_assert(R * (T + 1) * 8 >= 800, "tile must be able to hold the chain seeds");
+    // The chain seeds live in LDS only until every lane has pulled its own into
+    // registers; the tile then reuses the same bytes (keeps the workgroup at
+    // <= 20 KiB of LDS = 8 waves per CU, so 4,096 blocks are exactly 2 waves of
+    // residency on 256 CUs).
+    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * (T + 1)];   // +1 scratch row for lanes >= R
+    u32 *sW = reinterpret_cast<u32 *>(s_tile);   // [64]
+    u32 *sA = sW + 64;         // [68] sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
+    u32 *sE = sA + 68;         // [68] sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
+    __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
 
     const u32 lane = threadIdx.x;
-    const size_t blk = blockIdx.x;
+    const u32 parts = p.parts;                   // waves per block (power of two <= 16)
+    const size_t blk = blockIdx.x / parts;
+    const u32 part = blockIdx.x % parts;
 
     // ---- chain phase: plain SHA-256 of this block, wave-uniform -------------
     {
@@ -428,7 +517,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
             h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
             if (lane == 0) { sA[t + 4] = a; sE[t + 4] = e; }
         }
-        if (p.next_states != nullptr && lane == 0) {
+        if (p.next_states != nullptr && lane == 0 && part == 0) {
             u32 *ns = p.next_states + 8 * blk;               // compression.rs:197-212
             ns[0] = ps[0] + a; ns[1] = ps[1] + b; ns[2] = ps[2] + c; ns[3] = ps[3] + d;
             ns[4] = ps[4] + e; ns[5] = ps[5] + f; ns[6] = ps[6] + g; ns[7] = ps[7] + h;
@@ -436,127 +525,95 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     }
     __syncthreads();
 
-    Em<T> em;
+    // ---- every lane pulls the seeds of its units into registers -------------
+    auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };   // a..d = sA[3..0], e..h = sE[3..0]
+    const u32 u16_ = lane_unit(part, parts, 16), us = lane_unit(part, parts, 48);
+    const u32 ust = lane_unit(part, parts, 6), ur = lane_unit(part, parts, 64), uf = lane_unit(part, parts, 8);
+    const u32 seed_word = sW[u16_];
+    const u32 seed_w2 = sW[us + 14], seed_w15 = sW[us + 1], seed_w7 = sW[us + 9], seed_w16 = sW[us];
+    const u32 seed_state = pre_word(ust < 3 ? ust : ust + 1);
+    const u32 seed_a = sA[ur + 3], seed_b = sA[ur + 2], seed_c = sA[ur + 1], seed_d = sA[ur];
+    const u32 seed_e = sE[ur + 3], seed_f = sE[ur + 2], seed_g = sE[ur + 1], seed_h = sE[ur];
+    const u32 seed_wr = sW[ur], seed_k = K256[ur];
+    const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
+    __syncthreads();           // seeds are in registers: the tile may now overwrite them
+
+    Em<T, R> em;
     em.tile = s_tile;
-    em.row = s_tile + lane * (T + 1);
+    em.row = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 1);   // lanes >= R never flush: scratch row
     em.d16 = s_d16;
     em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)blk * (size_t)LY::GATE_CELLS * 2u;
     em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
-
-    // pre-state word i: a..d live in sA[3..0], e..h in sE[3..0]
-    auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };
+    const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
 
     // ---- words: compression.rs:31-47, 16 units of 4 mul_add ----------------
-    phase_begin<T>(em, 16, LY::WORD, LY::OFF_WORDS, 0, 0);
-    {
-        const u32 word = sW[lane & 15];
+    if (phase_begin<T, R>(em, part, parts, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
+        const u32 word = seed_word;
         u32 sum = 0;
 #pragma unroll
         for (int idx = 0; idx < 4; idx++) {                  // bytes[3 - idx] * 2^(8 idx) + sum
             const u32 byte = (word >> (8 * idx)) & 0xffu;
             const u32 ns = sum | (byte << (8 * idx));
-            g_mul_add<T>(em, byte, 1u << (8 * idx), sum, ns);
+            g_mul_add<T, R>(em, byte, 1u << (8 * idx), sum, ns);
             sum = ns;
         }
+        phase_end<L, T, R>(em, p, blk_limb0);
     }
-    phase_end<T>(em);
 
     // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
-    phase_begin<T>(em, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S);
-    state_to_spread<L, T>(em, sW[lane & 15]);
-    phase_end<T>(em);
+    if (phase_begin<T, R>(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
+        state_to_spread<L, T, R>(em, seed_word);
+        phase_end<L, T, R>(em, p, blk_limb0);
+    }
 
     // ---- schedule: compression.rs:57-96, 48 units --------------------------
-    phase_begin<T>(em, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED);
-    {
-        const u32 idx = 16 + (lane < 48 ? lane : 47);
-        const u32 w2 = sW[idx - 2], w15 = sW[idx - 15], w7 = sW[idx - 7], w16 = sW[idx - 16];
-        const u32 term1 = sigma_generic<SigmaLower1, L, T>(em, w2);      // :60
-        const u32 term3 = sigma_generic<SigmaLower0, L, T>(em, w15);     // :61
-        u64 sum = g_add<T>(em, term1, w7);                               // :65-69
-        sum = g_add<T>(em, sum, term3);                                  // :70-74
-        sum = g_add<T>(em, sum, w16);                                    // :75-79
-        const u32 new_w = mod_u32<T>(em, sum);                           // :80
-        state_to_spread<L, T>(em, new_w);                                // :90
+    if (phase_begin<T, R>(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED)) {
+        const u32 w2 = seed_w2, w15 = seed_w15, w7 = seed_w7, w16 = seed_w16;   // W[idx-2], [idx-15], [idx-7], [idx-16]
+        const u32 term1 = sigma_generic<SigmaLower1, L, T, R>(em, w2);      // :60
+        const u32 term3 = sigma_generic<SigmaLower0, L, T, R>(em, w15);     // :61
+        u64 sum = g_add<T, R>(em, term1, w7);                               // :65-69
+        sum = g_add<T, R>(em, sum, term3);                                  // :70-74
+        sum = g_add<T, R>(em, sum, w16);                                    // :75-79
+        const u32 new_w = mod_u32<T, R>(em, sum);                           // :80
+        state_to_spread<L, T, R>(em, new_w);                                // :90
+        phase_end<L, T, R>(em, p, blk_limb0);
     }
-    phase_end<T>(em);
 
     // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
-    phase_begin<T>(em, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S);
-    {
-        const u32 j = lane < 6 ? lane : 5;
-        state_to_spread<L, T>(em, pre_word(j < 3 ? j : j + 1));
+    if (phase_begin<T, R>(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
+        state_to_spread<L, T, R>(em, seed_state);
+        phase_end<L, T, R>(em, p, blk_limb0);
     }
-    phase_end<T>(em);
 
     // ---- 64 rounds: compression.rs:125-196 ---------------------------------
-    phase_begin<T>(em, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND);
-    {
-        const u32 r = lane;
-        const u32 a = sA[r + 3], b = sA[r + 2], c = sA[r + 1], d = sA[r];
-        const u32 e = sE[r + 3], f = sE[r + 2], g = sE[r + 1], h = sE[r];
-        const u32 sig1 = sigma_generic<SigmaUpper1, L, T>(em, e);        // :130
-        const u32 chv = ch_gadget<L, T>(em, e, f, g);                    // :131
-        u64 s = g_add<T>(em, h, sig1);                                   // :138-142
-        s = g_add<T>(em, s, chv);                                        // :143-147
-        s = g_add<T>(em, s, K256[r]);                                    // :148-152
-        s = g_add<T>(em, s, sW[r]);                                      // :153-157
-        const u32 t1 = mod_u32<T>(em, s);                                // :158
-        const u32 sig0 = sigma_generic<SigmaUpper0, L, T>(em, a);        // :164
-        const u32 mjv = maj_gadget<L, T>(em, a, b, c);                   // :165
-        s = g_add<T>(em, sig0, mjv);                                     // :166-170
-        const u32 t2 = mod_u32<T>(em, s);                                // :171
-        s = g_add<T>(em, d, t1);                                         // :181
-        const u32 e_new = mod_u32<T>(em, s);                             // :182
-        state_to_spread<L, T>(em, e_new);                                // :184
-        s = g_add<T>(em, t1, t2);                                        // :192
-        const u32 a_new = mod_u32<T>(em, s);                             // :193
-        state_to_spread<L, T>(em, a_new);                                // :195
+    if (phase_begin<T, R>(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND)) {
+        const u32 a = seed_a, b = seed_b, c = seed_c, d = seed_d;
+        const u32 e = seed_e, f = seed_f, g = seed_g, h = seed_h;
+        const u32 sig1 = sigma_generic<SigmaUpper1, L, T, R>(em, e);        // :130
+        const u32 chv = ch_gadget<L, T, R>(em, e, f, g);                    // :131
+        u64 s = g_add<T, R>(em, h, sig1);                                   // :138-142
+        s = g_add<T, R>(em, s, chv);                                        // :143-147
+        s = g_add<T, R>(em, s, seed_k);                                     // :148-152
+        s = g_add<T, R>(em, s, seed_wr);                                    // :153-157
+        const u32 t1 = mod_u32<T, R>(em, s);                                // :158
+        const u32 sig0 = sigma_generic<SigmaUpper0, L, T, R>(em, a);        // :164
+        const u32 mjv = maj_gadget<L, T, R>(em, a, b, c);                   // :165
+        s = g_add<T, R>(em, sig0, mjv);                                     // :166-170
+        const u32 t2 = mod_u32<T, R>(em, s);                                // :171
+        s = g_add<T, R>(em, d, t1);                                         // :181
+        const u32 e_new = mod_u32<T, R>(em, s);                             // :182
+        state_to_spread<L, T, R>(em, e_new);                                // :184
+        s = g_add<T, R>(em, t1, t2);                                        // :192
+        const u32 a_new = mod_u32<T, R>(em, s);                             // :193
+        state_to_spread<L, T, R>(em, a_new);                                // :195
+        phase_end<L, T, R>(em, p, blk_limb0);
     }
-    phase_end<T>(em);
 
     // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
-    phase_begin<T>(em, 8, LY::FEED, LY::OFF_FEED, 0, 0);
-    {
-        const u32 i = lane & 7;
-        const u32 x = i < 4 ? sA[67 - i] : sE[71 - i];
-        const u64 s = g_add<T>(em, x, pre_word(i));
-        mod_u32<T>(em, s);
-    }
-    phase_end<T>(em);
-
-    // ---- chip pass: spread.rs:196-233 column placement ---------------------
-    // limb call n (absolute, counted from SpreadConfig.num_limb_sum = 0) lands
-    // in column n % ncols, row n / ncols; buffer row 0 = row cursor0 / ncols.
-    if ((p.flags & HSW_K_SKIP_CHIP) == 0u) {
-        constexpr int B = LY::LIMB_BITS;
-        constexpr u32 MASK = (1u << B) - 1u;
-        const u64 ncols = p.ncols;
-        const u64 first = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
-        const u64 last = first + (u64)LY::LIMB_CALLS - 1;               // last one
-        const u64 row0 = p.cursor0 / ncols;
-        uint4 *cd = reinterpret_cast<uint4 *>(p.chip_dense);
-        uint4 *cs = reinterpret_cast<uint4 *>(p.chip_spread);
-        for (u64 c = 0; c < ncols; c++) {
-            if (last < c) continue;
-            const u64 row_lo = (first + ncols - 1 - c) / ncols;         // first row with row*ncols + c >= first
-            const u64 row_hi = (last - c) / ncols;                      // last row with row*ncols + c <= last
-            if (row_hi < row_lo) continue;
-            const u32 count = (u32)(row_hi - row_lo + 1);
-            const u32 n0 = (u32)(row_lo * ncols + c - first);           // block-relative limb index of row_lo
-            const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
-            for (u32 i = lane; i < 2u * count; i += 64) {
-                const u32 k = i >> 1, hpart = i & 1u;
-                const u32 n = n0 + k * (u32)ncols;
-                const u32 call = n / L, j = n % L;
-                const u32 limb = ((u32)s_d16[call] >> (B * j)) & MASK;
-                uint4 od, os;
-                od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
-                os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
-                cd[base + i] = od;
-                cs[base + i] = os;
-            }
-        }
+    if (phase_begin<T, R>(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0)) {
+        const u64 s = g_add<T, R>(em, seed_fx, seed_fy);
+        mod_u32<T, R>(em, s);
+        phase_end<L, T, R>(em, p, blk_limb0);
     }
 }
 
@@ -599,20 +656,46 @@ __global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, si
     }
 }
 
-// ------------------------------------------------------------------ launch
-template <int L>
-static hipError_t launch_expand_L(const ExpandParams &p, hipStream_t stream) {
-    constexpr int T = 32;
-    if (p.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((hsw_expand_kernel<L, T>), dim3((unsigned)p.n_blocks), dim3(64), 0, stream, p);
+// Plain streaming fill, 16 B per lane, grid-stride: the practical HBM write
+// ceiling the expand kernel is compared against (bench.py "calibrated").
+__global__ __launch_bounds__(256) void hsw_fill_kernel(uint4 *dst, size_t n16, uint4 v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = v;
+}
+
+hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    uint4 v; v.x = 0x01010101u; v.y = 0; v.z = 0; v.w = 0;
+    hipLaunchKernelGGL(hsw_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<uint4 *>(dst), n16, v);
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const ExpandParams &p, int limbs, hipStream_t stream) {
+// ------------------------------------------------------------------ launch
+template <int L, int T, int R>
+static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
+    if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
+    hipLaunchKernelGGL((hsw_expand_kernel<L, T, R>), dim3((unsigned)(p.n_blocks * p.parts)), dim3(64), 0,
+                       stream, p);
+    return hipGetLastError();
+}
+
+template <int L>
+static hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
+    if (p.n_blocks == 0) return hipSuccess;
+    switch (tile) {
+        case 32: return launch_expand_LTR<L, 32, 64>(p, stream);
+        case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32>(p, stream); else return hipErrorInvalidValue;
+        case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16>(p, stream); else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t stream) {
     switch (limbs) {
-        case 1: return launch_expand_L<1>(p, stream);
-        case 2: return launch_expand_L<2>(p, stream);
-        case 4: return launch_expand_L<4>(p, stream);
+        case 1: return launch_expand_L<1>(p, tile, stream);
+        case 2: return launch_expand_L<2>(p, tile, stream);
+        case 4: return launch_expand_L<4>(p, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -103,6 +103,16 @@ class WitnessEngine:
         self._ok(rc)
         return pre
 
+    def set_option(self, name, value):
+        self._ok(self.lib.hsw_engine_set_option(self.h, name.encode(), int(value)))
+
+    def fill_calibrate(self, tensor):
+        """Plain streaming fill of `tensor`'s bytes; returns milliseconds."""
+        ms = C.c_float()
+        self._ok(self.lib.hsw_fill_calibrate(self.h, tensor.data_ptr(), tensor.numel() * tensor.element_size(),
+                                             C.byref(ms)))
+        return float(ms.value)
+
     def set_timing(self, on=True):
         self._ok(self.lib.hsw_set_timing(self.h, 1 if on else 0))
 

@@ -156,6 +156,16 @@ int hsw_last_kernel_ms(hsw_engine *e, float *ms);
 /* Enable/disable the per-launch event pair (off by default: no overhead). */
 int hsw_set_timing(hsw_engine *e, int enabled);
 
+/* Calibration: overwrites `bytes` of d_buf with a plain 16-byte-per-lane
+ * streaming fill and returns its duration -- the practical HBM write ceiling
+ * of this device/allocation, which bench.py reports next to the 8 TB/s spec. */
+int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
+
+/* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
+ * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
+ * contiguous run of one unit, 32 (default), 64 or 128. */
+int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
+
 const char *hsw_strerror(int status);
 /* Detail of the last failure on this engine ("" if none); never NULL. */
 const char *hsw_last_error(const hsw_engine *e);
