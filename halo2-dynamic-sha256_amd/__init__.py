@@ -12,7 +12,9 @@ import it with importlib:
 from . import _native
 from ._native import (HSW_OK, HSW_REPR_CANONICAL, HSW_REPR_MONTGOMERY, HSW_SKIP_CHIP,
                       HSW_SKIP_GATE, HswError, Shape, build, shape_query)
+from ._native import digest_prepare
 from .engine import WitnessEngine
+from .gadget import AssignedHashResult, Sha256DynamicConfig
 
-__all__ = ["WitnessEngine", "HswError", "Shape", "shape_query", "build", "_native",
+__all__ = ["WitnessEngine", "Sha256DynamicConfig", "AssignedHashResult", "digest_prepare", "HswError", "Shape", "shape_query", "build", "_native",
            "HSW_OK", "HSW_REPR_CANONICAL", "HSW_REPR_MONTGOMERY", "HSW_SKIP_GATE", "HSW_SKIP_CHIP"]

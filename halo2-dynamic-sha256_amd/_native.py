@@ -40,12 +40,32 @@ class Shape(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class DigestInfo(C.Structure):
+    _fields_ = [("num_round", C.c_size_t), ("precomputed_round", C.c_size_t),
+                ("target_round", C.c_size_t), ("n_blocks", C.c_size_t)]
+
+
+class HashResult(C.Structure):
+    _fields_ = [("input_len", C.c_uint64), ("first_block", C.c_size_t), ("n_blocks", C.c_size_t),
+                ("spread_cursor0", C.c_uint64), ("num_round", C.c_size_t), ("target_round", C.c_size_t),
+                ("output_bytes", C.c_uint8 * 32)]
+
+
+class GadgetView(C.Structure):
+    _fields_ = [("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p), ("d_chip_spread", C.c_void_p),
+                ("d_next_states", C.c_void_p), ("chip_col_stride", C.c_size_t), ("blocks_done", C.c_size_t),
+                ("capacity_blocks", C.c_size_t), ("num_limb_sum", C.c_uint64), ("cur_hash_idx", C.c_size_t)]
+
+
 # every symbol include/hsw.h declares (tests check the library exports them all)
 SYMBOLS = (
     "hsw_shape_query", "hsw_chip_rows", "hsw_engine_create", "hsw_engine_destroy",
     "hsw_engine_shape", "hsw_engine_synchronize", "hsw_witness_blocks", "hsw_sha256_chain",
     "hsw_witness_blocks_host", "hsw_last_kernel_ms", "hsw_set_timing", "hsw_strerror",
     "hsw_last_error", "hsw_abi_version", "hsw_engine_set_option", "hsw_fill_calibrate",
+    "hsw_engine_stream", "hsw_digest_prepare", "hsw_gadget_create", "hsw_gadget_destroy",
+    "hsw_gadget_digest", "hsw_gadget_digest_batch", "hsw_gadget_streams", "hsw_gadget_input_bytes",
+    "hsw_gadget_set_repr", "hsw_download",
 )
 
 
@@ -107,6 +127,28 @@ def lib():
         L.hsw_fill_calibrate.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_float)]
     L.hsw_set_timing.restype = C.c_int
     L.hsw_set_timing.argtypes = [vp, C.c_int]
+    if hasattr(L, "hsw_gadget_create"):
+        L.hsw_engine_stream.restype = C.c_int
+        L.hsw_engine_stream.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
+        L.hsw_digest_prepare.restype = C.c_int
+        L.hsw_digest_prepare.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(DigestInfo)]
+        L.hsw_gadget_create.restype = C.c_int
+        L.hsw_gadget_create.argtypes = [vp, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.POINTER(vp)]
+        L.hsw_gadget_destroy.restype = None
+        L.hsw_gadget_destroy.argtypes = [vp]
+        L.hsw_gadget_digest.restype = C.c_int
+        L.hsw_gadget_digest.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(HashResult)]
+        L.hsw_gadget_digest_batch.restype = C.c_int
+        L.hsw_gadget_digest_batch.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_size_t), C.POINTER(HashResult)]
+        L.hsw_gadget_streams.restype = C.c_int
+        L.hsw_gadget_streams.argtypes = [vp, C.POINTER(GadgetView)]
+        L.hsw_gadget_input_bytes.restype = C.c_int
+        L.hsw_gadget_input_bytes.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hsw_download.restype = C.c_int
+        L.hsw_download.argtypes = [vp, vp, vp, C.c_size_t]
+        L.hsw_gadget_set_repr.restype = C.c_int
+        L.hsw_gadget_set_repr.argtypes = [vp, C.c_uint32]
     _lib = L
     return L
 
@@ -116,6 +158,21 @@ class HswError(RuntimeError):
         self.status = status
         msg = lib().hsw_strerror(status).decode()
         super().__init__("hsw status %d (%s)%s" % (status, msg, (": " + detail) if detail else ""))
+
+
+def digest_prepare(message: bytes, max_variable_byte_size: int, precomputed_input_len: int = 0):
+    """Host-only lib.rs:77-160: returns (blocks bytes, init_state list, DigestInfo dict)."""
+    import numpy as np
+    msg = bytes(message)
+    buf = (C.c_uint8 * max(len(msg), 1)).from_buffer_copy(msg if msg else b"\0")
+    blocks = np.zeros(max(max_variable_byte_size, 1), dtype=np.uint8)
+    init = np.zeros(8, dtype=np.uint32)
+    info = DigestInfo()
+    rc = lib().hsw_digest_prepare(C.addressof(buf) if msg else None, len(msg), precomputed_input_len,
+                                  max_variable_byte_size, blocks.ctypes.data, init.ctypes.data, C.byref(info))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return blocks[:max_variable_byte_size], init, {k: int(getattr(info, k)) for k, _ in DigestInfo._fields_}
 
 
 def shape_query(num_bits_lookup=8, num_advice_columns=2):

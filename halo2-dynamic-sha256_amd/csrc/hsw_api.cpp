@@ -183,6 +183,13 @@ int hsw_engine_shape(const hsw_engine *e, hsw_shape *out) {
     return HSW_OK;
 }
 
+int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (hip_stream) *hip_stream = e->stream;
+    if (device) *device = e->device;
+    return HSW_OK;
+}
+
 int hsw_engine_synchronize(hsw_engine *e) {
     if (!e) return HSW_ERR_INVALID_ARG;
     DeviceScope ds(e->device);
@@ -299,6 +306,17 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
         e->timed = true;
     }
+    return HSW_OK;
+}
+
+int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes) {
+    if (!e || (bytes && (!host_dst || !d_src))) return HSW_ERR_INVALID_ARG;
+    if (bytes == 0) return HSW_OK;
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipError_t he = hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_download", he);
     return HSW_OK;
 }
 

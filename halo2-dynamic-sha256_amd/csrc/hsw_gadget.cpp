@@ -1,0 +1,386 @@
+// hsw_gadget.cpp -- Sha256DynamicConfig / Context mirror (see hsw_gadget.hpp)
+// and its C ABI (include/hsw.h, "gadget front-end").
+#include "hsw_gadget.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "hsw_kernels.h"
+
+namespace hsw {
+
+namespace {
+
+const uint32_t K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+const uint32_t INIT_STATE[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,      // compression.rs:1003-1012
+                                0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+// What sha2::compress256 does for the precomputed prefix (lib.rs:160).  The
+// prefix is by definition NOT part of the circuit, so the reference hashes it
+// on the CPU too; this is not a fallback of the witness path.
+void plain_compress(uint32_t st[8], const uint8_t *block) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)block[4 * i] << 24) | ((uint32_t)block[4 * i + 1] << 16) |
+               ((uint32_t)block[4 * i + 2] << 8) | block[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+int digest_prepare(const uint8_t *input, size_t input_byte_size, size_t precomputed_input_len,
+                   size_t max_variable_byte_size, DigestPlan *plan) {
+    if (!plan || (!input && input_byte_size)) return HSW_ERR_INVALID_ARG;
+    const size_t one_round_size = 64;                                         // lib.rs:48
+    if (max_variable_byte_size % one_round_size != 0) return HSW_ERR_SHAPE;   // lib.rs:57-59
+    const size_t input_byte_size_with_9 = input_byte_size + 9;                // lib.rs:78
+    const size_t num_round = (input_byte_size_with_9 + one_round_size - 1) / one_round_size;   // lib.rs:80-84
+    const size_t padded_size = one_round_size * num_round;                    // lib.rs:85
+    if (precomputed_input_len % one_round_size != 0) return HSW_ERR_SHAPE;    // lib.rs:89
+    if (precomputed_input_len > padded_size ||
+        padded_size - precomputed_input_len > max_variable_byte_size)
+        return HSW_ERR_TOO_LARGE;                                             // lib.rs:90
+    const size_t zero_padding_byte_size = padded_size - input_byte_size_with_9;               // lib.rs:91
+    const size_t remaining_byte_size = max_variable_byte_size + precomputed_input_len - padded_size;   // lib.rs:92
+    const size_t precomputed_round = precomputed_input_len / one_round_size;  // lib.rs:93
+    const size_t total = max_variable_byte_size + precomputed_input_len;
+
+    std::vector<uint8_t> padded(total, 0);                                    // lib.rs:98-117
+    if (input_byte_size) std::memcpy(padded.data(), input, input_byte_size);
+    size_t n = input_byte_size;
+    padded[n++] = 0x80;                                                       // lib.rs:99
+    n += zero_padding_byte_size;                                              // lib.rs:100-102
+    const uint64_t bitlen = 8ull * (uint64_t)input_byte_size;                 // lib.rs:103-108 (big-endian)
+    for (int i = 7; i >= 0; i--) padded[n++] = (uint8_t)(bitlen >> (8 * i));
+    if (n != num_round * one_round_size) return HSW_ERR_INVALID_ARG;          // lib.rs:110
+    if (n + remaining_byte_size != total) return HSW_ERR_INVALID_ARG;         // lib.rs:111-117
+
+    std::memcpy(plan->init_state, INIT_STATE, sizeof INIT_STATE);             // lib.rs:155
+    for (size_t r = 0; r < precomputed_round; r++)                            // lib.rs:156-160
+        plain_compress(plan->init_state, padded.data() + r * one_round_size);
+    plan->blocks.assign(padded.begin() + (ptrdiff_t)precomputed_input_len, padded.end());   // lib.rs:170
+    plan->num_round = num_round;
+    plan->precomputed_round = precomputed_round;
+    plan->target_round = num_round - precomputed_round;
+    plan->max_variable_round = max_variable_byte_size / one_round_size;
+    return HSW_OK;
+}
+
+int Sha256DynamicConfig::configure(const std::vector<size_t> &sizes, uint32_t num_bits_lookup,
+                                   uint32_t num_advice_columns, bool is_input_range_check,
+                                   Sha256DynamicConfig *out) {
+    if (!out) return HSW_ERR_INVALID_ARG;
+    for (size_t b : sizes)
+        if (b % 64 != 0) return HSW_ERR_SHAPE;                                // lib.rs:57-59
+    hsw_shape s;
+    const int rc = hsw_shape_query(num_bits_lookup, num_advice_columns, &s);  // SpreadConfig::configure, spread.rs:37
+    if (rc != HSW_OK) return rc;
+    out->max_variable_byte_sizes = sizes;
+    out->cur_hash_idx = 0;                                                    // lib.rs:66
+    out->num_bits_lookup = num_bits_lookup;
+    out->num_advice_columns = num_advice_columns;
+    out->is_input_range_check = is_input_range_check;
+    return HSW_OK;
+}
+
+std::vector<std::pair<uint64_t, uint64_t>> Sha256DynamicConfig::load() const {
+    std::vector<std::pair<uint64_t, uint64_t>> rows;                          // spread.rs:169-189
+    for (uint64_t idx = 0; idx < (1ull << num_bits_lookup); idx++) {
+        uint64_t sp = 0;
+        for (int b = 0; b < 32; b++) sp |= ((idx >> b) & 1ull) << (2 * b);
+        rows.emplace_back(idx, sp);
+    }
+    return rows;
+}
+
+Context::~Context() {
+    (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
+    (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
+    (void)hipFree(d_init_states);
+}
+
+int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out) const {
+    if (!engine || !out) return HSW_ERR_INVALID_ARG;
+    *out = nullptr;
+    hsw_shape s;
+    int rc = hsw_engine_shape(engine, &s);
+    if (rc != HSW_OK) return rc;
+    if (s.num_bits_lookup != num_bits_lookup || s.num_advice_columns != num_advice_columns)
+        return HSW_ERR_SHAPE;
+    Context *c = new (std::nothrow) Context();
+    if (!c) return HSW_ERR_NOMEM;
+    c->engine = engine;
+    c->shape = s;
+    size_t total = 0;
+    for (size_t b : max_variable_byte_sizes) total += b / 64;
+    c->capacity_blocks = total;
+    c->chip_col_stride = (size_t)hsw_chip_rows(&s, 0, total);
+    c->init_capacity = max_variable_byte_sizes.size();
+    const size_t nb = total ? total : 1, nh = c->init_capacity ? c->init_capacity : 1;
+    hipError_t he = hipMalloc(&c->d_gate, nb * (size_t)s.gate_cells_per_block * HSW_CELL_BYTES);
+    const size_t col_bytes = (size_t)s.num_advice_columns * (c->chip_col_stride ? c->chip_col_stride : 1) * HSW_CELL_BYTES;
+    if (he == hipSuccess) he = hipMalloc(&c->d_chip_dense, col_bytes);
+    if (he == hipSuccess) he = hipMalloc(&c->d_chip_spread, col_bytes);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_next_states, nb * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_blocks, nb * 64);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_pre_states, nb * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_init_states, nh * 32);
+    if (he == hipSuccess) he = hipMemset(c->d_chip_dense, 0, col_bytes);
+    if (he == hipSuccess) he = hipMemset(c->d_chip_spread, 0, col_bytes);
+    if (he != hipSuccess) {
+        delete c;
+        return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+    }
+    *out = c;
+    return HSW_OK;
+}
+
+int Sha256DynamicConfig::digest(Context &ctx, const uint8_t *input, size_t input_len,
+                                size_t precomputed_input_len, AssignedHashResult *result) {
+    return digest_batch(ctx, 1, &input, &input_len, &precomputed_input_len, result);
+}
+
+int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *const *inputs,
+                                      const size_t *input_lens, const size_t *precomputed_input_lens,
+                                      AssignedHashResult *results) {
+    if (!results || !inputs || !input_lens) return HSW_ERR_INVALID_ARG;
+    if (n == 0) return HSW_OK;
+    // max_variable_byte_sizes[cur_hash_idx] must exist for every hash (lib.rs:86 would panic)
+    if (cur_hash_idx + n > max_variable_byte_sizes.size()) return HSW_ERR_INVALID_ARG;
+
+    // ---- host: lib.rs:77-160 for every message; nothing is committed on error ----
+    std::vector<DigestPlan> plans(n);
+    size_t batch_blocks = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t max_sz = max_variable_byte_sizes[cur_hash_idx + i];
+        const int rc = digest_prepare(inputs[i], input_lens[i],
+                                      precomputed_input_lens ? precomputed_input_lens[i] : 0, max_sz, &plans[i]);
+        if (rc != HSW_OK) return rc;
+        batch_blocks += plans[i].max_variable_round;
+    }
+    if (ctx.blocks_done + batch_blocks > ctx.capacity_blocks || n > ctx.init_capacity) return HSW_ERR_INVALID_ARG;
+
+    std::vector<uint8_t> h_blocks(batch_blocks * 64 ? batch_blocks * 64 : 1);
+    std::vector<uint32_t> h_init(n * 8), h_offsets(n + 1);
+    size_t off = 0;
+    for (size_t i = 0; i < n; i++) {
+        h_offsets[i] = (uint32_t)off;
+        if (!plans[i].blocks.empty()) std::memcpy(h_blocks.data() + off * 64, plans[i].blocks.data(), plans[i].blocks.size());
+        std::memcpy(&h_init[8 * i], plans[i].init_state, 32);
+        off += plans[i].max_variable_round;
+    }
+    h_offsets[n] = (uint32_t)off;
+
+    // ---- device: chain pre-pass + ONE expansion launch for the whole batch ----
+    hipStream_t stream = nullptr;
+    int device = 0;
+    hsw_engine_stream(ctx.engine, reinterpret_cast<void **>(&stream), &device);
+    DeviceScope ds(device);
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
+    const size_t b0 = ctx.blocks_done;
+    uint8_t *d_blk = ctx.d_blocks + 64 * b0;
+    uint32_t *d_pre = ctx.d_pre_states + 8 * b0;
+    uint32_t *d_next = ctx.d_next_states + 8 * b0;
+    uint32_t *d_off = nullptr;
+    std::vector<uint32_t> h_next(batch_blocks * 8 ? batch_blocks * 8 : 1);
+    hipError_t he = hipSuccess;
+    int rc = HSW_OK;
+    do {
+        if (batch_blocks == 0) break;
+        if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
+        if ((he = hipMemcpyAsync(d_blk, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
+        const size_t G = ctx.shape.gate_cells_per_block;
+        // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
+        // Column buffers are addressed from absolute row 0 (cursor origin of the context).
+        const uint64_t row_shift = ctx.num_limb_sum / ctx.shape.num_advice_columns;
+        rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
+                                static_cast<uint8_t *>(ctx.d_gate) + b0 * G * HSW_CELL_BYTES,
+                                static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * HSW_CELL_BYTES,
+                                static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES,
+                                ctx.chip_col_stride, d_next, ctx.repr_flags);
+        if (rc != HSW_OK) break;
+        if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        he = hipStreamSynchronize(stream);
+    } while (0);
+    (void)hipFree(d_off);
+    if (rc != HSW_OK) return rc;
+    if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+
+    // ---- results: the "select state #target_round" rule (lib.rs:294-310) ----
+    off = 0;
+    for (size_t i = 0; i < n; i++) {
+        AssignedHashResult &r = results[i];
+        const DigestPlan &pl = plans[i];
+        r.input_len = input_lens[i];
+        r.input_bytes = pl.blocks;
+        r.first_block = b0 + off;
+        r.n_blocks = pl.max_variable_round;
+        r.spread_cursor0 = ctx.num_limb_sum + (uint64_t)off * ctx.shape.limb_calls_per_block;
+        r.num_round = pl.num_round;
+        r.target_round = pl.target_round;
+        uint32_t sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // output_h_out starts as zero cells (lib.rs:294-295)
+        if (pl.target_round == 0) std::memcpy(sel, pl.init_state, 32);                 // candidate 0
+        else if (pl.target_round <= pl.max_variable_round)
+            std::memcpy(sel, &h_next[8 * (off + pl.target_round - 1)], 32);            // candidate target_round
+        for (int w = 0; w < 8; w++) {                           // lib.rs:311-341 big-endian bytes
+            r.output_bytes[4 * w] = (uint8_t)(sel[w] >> 24);
+            r.output_bytes[4 * w + 1] = (uint8_t)(sel[w] >> 16);
+            r.output_bytes[4 * w + 2] = (uint8_t)(sel[w] >> 8);
+            r.output_bytes[4 * w + 3] = (uint8_t)sel[w];
+        }
+        off += pl.max_variable_round;
+    }
+    ctx.blocks_done += batch_blocks;
+    ctx.num_limb_sum += (uint64_t)batch_blocks * ctx.shape.limb_calls_per_block;   // spread.rs:228
+    cur_hash_idx += n;                                                             // lib.rs:347
+    return HSW_OK;
+}
+
+}  // namespace hsw
+
+// ------------------------------------------------------------------- C ABI
+struct hsw_gadget {
+    hsw::Sha256DynamicConfig cfg;
+    hsw::Context *ctx = nullptr;
+    std::vector<hsw::AssignedHashResult> results;   // one per digest so far (input_bytes kept for queries)
+};
+
+extern "C" {
+
+int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                       size_t max_variable_byte_size, uint8_t *blocks_out, uint32_t init_state_out[8],
+                       hsw_digest_info *info) {
+    hsw::DigestPlan plan;
+    const int rc = hsw::digest_prepare(input, input_len, precomputed_input_len, max_variable_byte_size, &plan);
+    if (rc != HSW_OK) return rc;
+    if (blocks_out && !plan.blocks.empty()) std::memcpy(blocks_out, plan.blocks.data(), plan.blocks.size());
+    if (init_state_out) std::memcpy(init_state_out, plan.init_state, 32);
+    if (info) {
+        info->num_round = plan.num_round;
+        info->precomputed_round = plan.precomputed_round;
+        info->target_round = plan.target_round;
+        info->n_blocks = plan.max_variable_round;
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                      int is_input_range_check, hsw_gadget **out) {
+    if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
+    *out = nullptr;
+    hsw_shape s;
+    int rc = hsw_engine_shape(e, &s);
+    if (rc != HSW_OK) return rc;
+    hsw_gadget *g = new (std::nothrow) hsw_gadget();
+    if (!g) return HSW_ERR_NOMEM;
+    std::vector<size_t> sizes(max_variable_byte_sizes, max_variable_byte_sizes + n_hashes);
+    rc = hsw::Sha256DynamicConfig::configure(sizes, s.num_bits_lookup, s.num_advice_columns,
+                                             is_input_range_check != 0, &g->cfg);
+    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx);
+    if (rc != HSW_OK) { delete g; return rc; }
+    *out = g;
+    return HSW_OK;
+}
+
+void hsw_gadget_destroy(hsw_gadget *g) {
+    if (!g) return;
+    delete g->ctx;
+    delete g;
+}
+
+static void fill_result(const hsw::AssignedHashResult &r, hsw_hash_result *o) {
+    o->input_len = r.input_len;
+    o->first_block = r.first_block;
+    o->n_blocks = r.n_blocks;
+    o->spread_cursor0 = r.spread_cursor0;
+    o->num_round = r.num_round;
+    o->target_round = r.target_round;
+    std::memcpy(o->output_bytes, r.output_bytes, 32);
+}
+
+int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs, const size_t *input_lens,
+                            const size_t *precomputed_input_lens, hsw_hash_result *results) {
+    if (!g || !results) return HSW_ERR_INVALID_ARG;
+    std::vector<hsw::AssignedHashResult> rs(n);
+    const int rc = g->cfg.digest_batch(*g->ctx, n, inputs, input_lens, precomputed_input_lens, rs.data());
+    if (rc != HSW_OK) return rc;
+    for (size_t i = 0; i < n; i++) {
+        fill_result(rs[i], &results[i]);
+        g->results.push_back(std::move(rs[i]));
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                      hsw_hash_result *result) {
+    return hsw_gadget_digest_batch(g, 1, &input, &input_len, &precomputed_input_len, result);
+}
+
+int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
+    if (!g || !view) return HSW_ERR_INVALID_ARG;
+    view->d_gate = g->ctx->d_gate;
+    view->d_chip_dense = g->ctx->d_chip_dense;
+    view->d_chip_spread = g->ctx->d_chip_spread;
+    view->d_next_states = g->ctx->d_next_states;
+    view->chip_col_stride = g->ctx->chip_col_stride;
+    view->blocks_done = g->ctx->blocks_done;
+    view->capacity_blocks = g->ctx->capacity_blocks;
+    view->num_limb_sum = g->ctx->num_limb_sum;
+    view->cur_hash_idx = g->cfg.cur_hash_idx;
+    return HSW_OK;
+}
+
+int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len) {
+    if (!g || hash_idx >= g->results.size()) return HSW_ERR_INVALID_ARG;
+    const std::vector<uint8_t> &b = g->results[hash_idx].input_bytes;
+    if (len) *len = b.size();
+    if (out) {
+        if (cap < b.size()) return HSW_ERR_INVALID_ARG;
+        if (!b.empty()) std::memcpy(out, b.data(), b.size());
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) {
+    if (!g || (repr & ~HSW_REPR_MASK)) return HSW_ERR_INVALID_ARG;
+    g->ctx->repr_flags = repr;
+    return HSW_OK;
+}
+
+}  // extern "C"

@@ -38,6 +38,8 @@ hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t
 hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_per_message,
                         const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
 
+hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
+                            const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 
 }  // namespace hsw

@@ -617,17 +617,14 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     }
 }
 
-// Plain SHA-256 chain pre-pass: one thread per message (hsw.h hsw_sha256_chain).
-__global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, size_t n_messages,
-                                                       size_t bpm, const u32 *init_states,
-                                                       u32 *pre_states) {
-    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_messages) return;
+// Plain SHA-256 chain of one message: writes the pre-state of each of its
+// blocks (what makes blocks independent for the expansion; lib.rs:188,236).
+DEV void chain_message(const uint8_t *blocks, size_t first_blk, size_t nblk, const u32 *init, u32 *pre_states) {
     u32 st[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) st[i] = init_states ? init_states[8 * m + i] : IV256[i];
-    for (size_t j = 0; j < bpm; j++) {
-        const size_t blk = m * bpm + j;
+    for (int i = 0; i < 8; i++) st[i] = init ? init[i] : IV256[i];
+    for (size_t j = 0; j < nblk; j++) {
+        const size_t blk = first_blk + j;
         const u32 *bw = reinterpret_cast<const u32 *>(blocks + 64 * blk);
 #pragma unroll
         for (int i = 0; i < 8; i++) pre_states[8 * blk + i] = st[i];
@@ -654,6 +651,26 @@ __global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, si
         st[0] += a; st[1] += b; st[2] += c; st[3] += d;
         st[4] += e; st[5] += f; st[6] += g; st[7] += h;
     }
+}
+
+// One thread per message, uniform blocks per message (hsw.h hsw_sha256_chain).
+__global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, size_t n_messages,
+                                                       size_t bpm, const u32 *init_states,
+                                                       u32 *pre_states) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_messages) return;
+    chain_message(blocks, m * bpm, bpm, init_states ? init_states + 8 * m : nullptr, pre_states);
+}
+
+// Ragged variant: message m owns blocks [offsets[m], offsets[m+1]) (gadget front-end:
+// hashes of one circuit may have different max_variable_byte_sizes, lib.rs:40,86).
+__global__ __launch_bounds__(64) void hsw_chain_var_kernel(const uint8_t *blocks, size_t n_messages,
+                                                           const u32 *offsets, const u32 *init_states,
+                                                           u32 *pre_states) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_messages) return;
+    chain_message(blocks, offsets[m], offsets[m + 1] - offsets[m],
+                  init_states ? init_states + 8 * m : nullptr, pre_states);
 }
 
 // Plain streaming fill, 16 B per lane, grid-stride: the practical HBM write
@@ -705,6 +722,15 @@ hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t bpm,
     if (n_messages == 0 || bpm == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n_messages + 63) / 64);
     hipLaunchKernelGGL(hsw_chain_kernel, dim3(grid), dim3(64), 0, stream, blocks, n_messages, bpm,
+                       init_states, pre_states);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
+                            const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream) {
+    if (n_messages == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_messages + 63) / 64);
+    hipLaunchKernelGGL(hsw_chain_var_kernel, dim3(grid), dim3(64), 0, stream, blocks, n_messages, offsets,
                        init_states, pre_states);
     return hipGetLastError();
 }

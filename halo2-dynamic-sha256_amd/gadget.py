@@ -1,0 +1,103 @@
+"""Python view of the C++ gadget front-end (csrc/hsw_gadget.hpp): the same
+names as the reference's `Sha256DynamicConfig` (src/lib.rs:38-369).  All logic
+lives in libhsw.so; this file only marshals arguments."""
+import ctypes as C
+
+from . import _native as N
+
+
+class AssignedHashResult:
+    """lib.rs:31-36 on values."""
+
+    def __init__(self, r, input_bytes):
+        self.input_len = int(r.input_len)
+        self.input_bytes = input_bytes
+        self.output_bytes = bytes(r.output_bytes)
+        self.first_block = int(r.first_block)
+        self.n_blocks = int(r.n_blocks)
+        self.spread_cursor0 = int(r.spread_cursor0)
+        self.num_round = int(r.num_round)
+        self.target_round = int(r.target_round)
+
+
+class Sha256DynamicConfig:
+    """configure (lib.rs:49-69) + new_context (lib.rs:351-360) in one object."""
+
+    def __init__(self, engine, max_variable_byte_sizes, is_input_range_check=True):
+        self.engine = engine
+        self.lib = engine.lib
+        self.max_variable_byte_sizes = list(max_variable_byte_sizes)
+        arr = (C.c_size_t * max(len(self.max_variable_byte_sizes), 1))(*self.max_variable_byte_sizes)
+        h = C.c_void_p()
+        rc = self.lib.hsw_gadget_create(engine.h, arr, len(self.max_variable_byte_sizes),
+                                        1 if is_input_range_check else 0, C.byref(h))
+        if rc != N.HSW_OK:
+            raise N.HswError(rc, self.lib.hsw_last_error(engine.h).decode())
+        self.h = h
+        self._n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsw_gadget_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ok(self, rc):
+        if rc != N.HSW_OK:
+            raise N.HswError(rc, self.lib.hsw_last_error(self.engine.h).decode())
+
+    def _input_bytes(self, idx):
+        n = C.c_size_t()
+        self._ok(self.lib.hsw_gadget_input_bytes(self.h, idx, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * max(n.value, 1))()
+        self._ok(self.lib.hsw_gadget_input_bytes(self.h, idx, buf, n.value, None))
+        return bytes(buf[: n.value])
+
+    def digest(self, message: bytes, precomputed_input_len=None):
+        """lib.rs:71-349; precomputed_input_len None == the reference's Option::None."""
+        return self.digest_batch([message], [precomputed_input_len])[0]
+
+    def digest_batch(self, messages, precomputed_input_lens=None):
+        n = len(messages)
+        keep = [bytes(m) for m in messages]
+        bufs = [(C.c_uint8 * max(len(m), 1)).from_buffer_copy(m if m else b"\0") for m in keep]
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        lens = (C.c_size_t * n)(*[len(m) for m in keep])
+        pl = precomputed_input_lens or [None] * n
+        pre = (C.c_size_t * n)(*[int(p or 0) for p in pl])
+        res = (N.HashResult * n)()
+        self._ok(self.lib.hsw_gadget_digest_batch(self.h, n, ptrs, lens, pre, res))
+        out = [AssignedHashResult(res[i], self._input_bytes(self._n + i)) for i in range(n)]
+        self._n += n
+        return out
+
+    def set_repr(self, repr_flag):
+        self._ok(self.lib.hsw_gadget_set_repr(self.h, repr_flag))
+
+    def view(self):
+        v = N.GadgetView()
+        self._ok(self.lib.hsw_gadget_streams(self.h, C.byref(v)))
+        return v
+
+    def streams(self):
+        """Copies of the streams written so far, as numpy uint64 arrays."""
+        import numpy as np
+        v = self.view()
+        G = self.engine.G
+        ncols = self.engine.ncols
+
+        def grab(ptr, n_cells):
+            a = np.zeros((n_cells, 4), dtype=np.uint64)
+            self._ok(self.lib.hsw_download(self.engine.h, a.ctypes.data, ptr, n_cells * 32))
+            return a
+
+        rows = (int(v.num_limb_sum) + ncols - 1) // ncols
+        gate = grab(v.d_gate, int(v.blocks_done) * G)
+        dense = np.stack([grab(v.d_chip_dense + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
+        spread = np.stack([grab(v.d_chip_spread + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
+        return dict(gate=gate, dense=dense, spread=spread, rows=rows)

@@ -156,6 +156,76 @@ int hsw_last_kernel_ms(hsw_engine *e, float *ms);
 /* Enable/disable the per-launch event pair (off by default: no overhead). */
 int hsw_set_timing(hsw_engine *e, int enabled);
 
+/* The stream / device an engine was created on. */
+int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device);
+
+/* ------------------------------------------------------------------------
+ * Gadget front-end: the host side of Sha256DynamicConfig::digest
+ * (reference src/lib.rs:71-349) -- SHA-256 padding, zero fill up to the
+ * FIXED maximum size, prefix pre-hash, chaining, "select state #n" -- over
+ * the engine.  csrc/hsw_gadget.hpp holds the C++ class of the same name.
+ * ------------------------------------------------------------------------ */
+
+typedef struct hsw_digest_info {
+    size_t num_round;          /* real rounds incl. the precomputed ones (lib.rs:80-84) */
+    size_t precomputed_round;  /* lib.rs:93 */
+    size_t target_round;       /* num_round - precomputed_round (lib.rs:147-151) */
+    size_t n_blocks;           /* max_variable_byte_size / 64: compressions synthesised (lib.rs:87,180) */
+} hsw_digest_info;
+
+/* lib.rs:77-117,153-160 on the host, no GPU: pads `input`, returns the
+ * max_variable_byte_size bytes fed to the circuit (blocks_out, may be NULL)
+ * and the state after the precomputed prefix (init_state_out, may be NULL).
+ * HSW_ERR_SHAPE: max or precomputed length not a multiple of 64 (lib.rs:57-59,89);
+ * HSW_ERR_TOO_LARGE: padded message does not fit (lib.rs:90). */
+int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                       size_t max_variable_byte_size, uint8_t *blocks_out,
+                       uint32_t init_state_out[8], hsw_digest_info *info);
+
+typedef struct hsw_gadget hsw_gadget;   /* Sha256DynamicConfig + its Context */
+
+typedef struct hsw_hash_result {        /* AssignedHashResult (lib.rs:31-36) on values */
+    uint64_t input_len;                 /* lib.rs:124-125 */
+    size_t first_block;                 /* this hash's first block in the gadget's streams */
+    size_t n_blocks;
+    uint64_t spread_cursor0;            /* SpreadConfig.num_limb_sum when this digest began */
+    size_t num_round, target_round;
+    uint8_t output_bytes[32];           /* lib.rs:311-341 */
+} hsw_hash_result;
+
+typedef struct hsw_gadget_view {
+    void *d_gate;                       /* capacity_blocks * G cells (device) */
+    void *d_chip_dense, *d_chip_spread; /* ncols columns, chip_col_stride cells apart, row 0 = chip row 0 */
+    uint32_t *d_next_states;
+    size_t chip_col_stride;
+    size_t blocks_done, capacity_blocks;
+    uint64_t num_limb_sum;              /* spread.rs:26 */
+    size_t cur_hash_idx;                /* lib.rs:43 */
+} hsw_gadget_view;
+
+/* Sha256DynamicConfig::configure (lib.rs:49-69) + new_context (lib.rs:351-360):
+ * allocates HBM for sum(max_variable_byte_sizes)/64 blocks of streams. */
+int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                      int is_input_range_check, hsw_gadget **out);
+void hsw_gadget_destroy(hsw_gadget *g);
+/* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.
+ * Synchronous: returns once the streams of this hash are in HBM. */
+int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len,
+                      size_t precomputed_input_len, hsw_hash_result *result);
+/* n consecutive digest() calls as ONE kernel launch (results as if sequential). */
+int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs,
+                            const size_t *input_lens, const size_t *precomputed_input_lens,
+                            hsw_hash_result *results);
+int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view);
+/* AssignedHashResult.input_bytes of digest #hash_idx (the padded variable part). */
+int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len);
+/* HSW_REPR_CANONICAL (default) or HSW_REPR_MONTGOMERY for subsequent digests. */
+int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr);
+
+/* Synchronous device-to-host copy on the engine's stream (for callers that hold
+ * device pointers from hsw_gadget_streams but have no HIP binding of their own). */
+int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes);
+
 /* Calibration: overwrites `bytes` of d_buf with a plain 16-byte-per-lane
  * streaming fill and returns its duration -- the practical HBM write ceiling
  * of this device/allocation, which bench.py reports next to the 8 TB/s spec. */

@@ -1,0 +1,54 @@
+"""Host side of the gadget front-end (hsw_digest_prepare: lib.rs:77-160) --
+pure CPU arithmetic in libhsw.so, compared with the oracle's restatement."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+@pytest.mark.parametrize("vec", KATS["vectors"], ids=lambda v: v["cite"].split(" ")[0])
+def test_prepare_matches_oracle_on_reference_kats(hsw, oracle, vec):
+    msg = bytes.fromhex(vec["input_hex"])
+    blocks, init, info = hsw.digest_prepare(msg, 128, 0)
+    ref = oracle.Oracle(8, 2).digest(msg, 128)
+    assert np.array_equal(blocks.reshape(-1, 64), ref["blocks"])
+    assert np.array_equal(init, oracle.INIT_STATE)
+    assert info["n_blocks"] == 2 and info["precomputed_round"] == 0
+    assert info["num_round"] == info["target_round"] == (len(msg) + 9 + 63) // 64
+    # chaining the prepared blocks with plain SHA reproduces the KAT at the selected round
+    st = init.copy()
+    states = [st.copy()]
+    for b in blocks.reshape(-1, 64):
+        st = oracle.plain_compress(st, b)
+        states.append(st.copy())
+    sel = states[info["target_round"]]
+    assert b"".join(int(x).to_bytes(4, "big") for x in sel).hex() == vec["digest_hex"]
+
+
+@pytest.mark.parametrize("n,maxb,pre", [(0, 64, 0), (55, 64, 0), (56, 128, 0), (64, 128, 0), (119, 128, 0),
+                                        (192, 128, 128), (200, 256, 64), (1015, 1024, 0), (300, 1024, 256),
+                                        (183, 64, 128)])
+def test_prepare_boundaries(hsw, oracle, n, maxb, pre):
+    rng = np.random.default_rng(n * 31 + maxb)
+    msg = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    blocks, init, info = hsw.digest_prepare(msg, maxb, pre)
+    ref = oracle.Oracle(8, 2).digest(msg, maxb, pre)
+    assert np.array_equal(blocks.reshape(-1, 64), ref["blocks"])
+    assert np.array_equal(init, ref["pre_states"][0])
+    assert info["n_blocks"] == maxb // 64 and info["precomputed_round"] == pre // 64
+    assert ref["digest"] == hashlib.sha256(msg).digest()
+
+
+def test_prepare_errors_mirror_reference_asserts(hsw):
+    N = hsw._native
+    for args, status in [((b"x" * 120, 128, 0), N.HSW_ERR_TOO_LARGE),     # lib.rs:90
+                         ((b"x" * 100, 128, 32), N.HSW_ERR_SHAPE),        # lib.rs:89
+                         ((b"x", 100, 0), N.HSW_ERR_SHAPE),               # lib.rs:57-59
+                         ((b"x" * 10, 128, 128), N.HSW_ERR_TOO_LARGE)]:   # precomputed beyond the padded size
+        with pytest.raises(hsw.HswError) as ei:
+            hsw.digest_prepare(*args)
+        assert ei.value.status == status, args
