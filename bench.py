@@ -169,7 +169,10 @@ def main():
     pre_h = np.tile(iv, (n, 1))
     blocks = torch.from_numpy(blocks_h).to(dev)
     pre = torch.from_numpy(pre_h.view(np.int32)).to(dev)
-    cursor0 = rank * n * eng.limb_calls      # rows land where the serial reference would put them
+    sh = importlib.import_module("halo2-dynamic-sha256_amd.sharding")
+    start, count = sh.shard_range(n * world, world, rank)          # contiguous shard of the global batch
+    assert count == n
+    cursor0 = sh.shard_cursor(0, start, eng.limb_calls)            # rows land where the serial reference would put them
     out = eng.alloc_outputs(n, cursor0)
     eng.set_timing(True)
 
@@ -201,6 +204,12 @@ def main():
         step()
         kms.append(eng.last_kernel_ms())
     kernel_ms_avg = float(np.mean(kms))
+    # practical write ceiling of this device/allocation: plain 16 B/lane fill of the same gate buffer
+    fill_ms = min(eng.fill_calibrate(out["gate"]) for _ in range(3))
+    fill_gbs = out["gate"].numel() * 8 / (fill_ms * 1e-3) / 1e9
+    for _ in range(2):     # the fill clobbered the stream: regenerate before the checks below
+        step()
+    torch.cuda.synchronize()
 
     # spot-check (size-independent property): digest from next_states == hashlib
     import hashlib
@@ -240,30 +249,42 @@ def main():
         extra["config1_1KiB_message_16_blocks"] = {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt}
 
     if distributed and not args.no_extra:
-        # north_star's all-gather of witness columns over xGMI, bounded shard:
-        # 256 blocks (611 MB) per rank.  Reported separately, never in `value`.
-        nb = 256
-        shard = out["gate"][: nb * eng.G]
-        gathered = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, shard)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            dist.all_gather_into_tensor(gathered, shard)
-        torch.cuda.synchronize()
-        dist.barrier()
-        dt = (time.perf_counter() - t1) / reps
-        shard_bytes = shard.numel() * 8
-        extra["allgather"] = {"shard_bytes": shard_bytes, "ms": dt * 1e3,
-                              "recv_GBps_per_gpu": shard_bytes * (world - 1) / dt / 1e9,
-                              "blocks_per_s_if_gathered": nb * world / dt}
-        del gathered
+        # north_star's all-gather of witness columns over xGMI (RCCL), on a bounded
+        # shard: 256 blocks (543 MB of gate cells) per rank.  Reported separately,
+        # never in `value`.  Symmetric on all ranks; a failure is recorded, not fatal.
+        try:
+            nb = min(256, n)
+            shard = out["gate"][: nb * eng.G]
+            counts = [nb] * world
+            gathered = sh.allgather_gate(dist, shard, counts, eng.G)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                gathered = sh.allgather_gate(dist, shard, counts, eng.G)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = (time.perf_counter() - t1) / reps
+            shard_bytes = shard.numel() * 8
+            same = bool((gathered[rank * nb * eng.G:(rank + 1) * nb * eng.G] == shard).all())
+            extra["allgather"] = {"shard_bytes": shard_bytes, "ms": dt * 1e3, "own_shard_intact": same,
+                                  "recv_GBps_per_gpu": shard_bytes * (world - 1) / dt / 1e9,
+                                  "blocks_per_s_if_gathered": nb * world / dt}
+            del gathered
+        except Exception as ex:
+            extra["allgather"] = {"error": repr(ex)}
 
     result = None
     if rank == 0:
         achieved = alg_bytes * n / (kernel_ms_avg * 1e-3) / 1e9
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc["blocks_per_launch"] == n:
+                traffic = pmc["hbm_traffic_bytes_per_launch"]
+        except Exception:
+            pass
         result = {
             "metric": "SHA256 compression blocks/sec (witness assign), k=17 shape",
             "value": value,
@@ -290,8 +311,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "hsw_expand_kernel<2,32>",
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes; bytes per launch)" if traffic else None,
+                "calibrated_fill_GBps": fill_gbs,
+                "kernel": "hsw_expand_kernel<2,32,64>",
                 "kernel_ms": kernel_ms_avg,
                 "algorithmic_bytes_per_launch": alg_bytes * n,
             },
