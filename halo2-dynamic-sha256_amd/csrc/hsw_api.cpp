@@ -241,8 +241,6 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
     if (n_blocks == 0) return HSW_OK;
     if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP))
         return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
-    if ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY)
-        return set_err(e, HSW_ERR_UNSUPPORTED, "HSW_REPR_MONTGOMERY is not built yet");
     if (!d_blocks || !d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
     if (((uintptr_t)d_blocks & 3u) || ((uintptr_t)d_pre_states & 3u))
         return set_err(e, HSW_ERR_INVALID_ARG, "inputs must be 4-byte aligned");
@@ -284,7 +282,8 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         p.chip_col_stride = chip_col_stride;
         p.cursor0 = spread_cursor0;
         p.ncols = e->shape.num_advice_columns;
-        p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP);
+        p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP) |
+                  ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY ? hsw::HSW_K_MONTGOMERY : 0u);
         p.parts = (uint32_t)choose_parts(e, n_blocks);
         if (done != 0) {
             // later chunks: keep buffer row 0 fixed by pre-offsetting the column

@@ -89,21 +89,104 @@ DEV u32 even_bits(u32 x) {
     return x;
 }
 
+// ---------------------------------------------------------- Montgomery form
+// HSW_REPR_MONTGOMERY: a cell holds x * 2^256 mod p, halo2curves' in-memory Fr.
+// For x = lo + hi*2^32 < 2^64:  x*R mod p = lo*R + hi*R32 (mod p) with the
+// constants R = 2^256 mod p and R32 = 2^288 mod p, reduced by one Barrett step:
+// t < 2^288, q^ = floor((t >> 224) * floor(2^288/p) / 2^64) is q, q-1 or q-2,
+// so r = t - q^ p < 3p < 2^256 and at most two subtractions of p remain.
+struct Fe8 { u32 l[8]; };
+#define HSW_MU 0x54a474626ull      /* floor(2^288 / p) */
+
+DEV Fe8 fe_sub_p_if_geq(const Fe8 &a) {
+    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
+    Fe8 s;
+    long long br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const long long d = (long long)a.l[j] - (long long)P[j] + br;
+        s.l[j] = (u32)d;
+        br = d >> 32;                          // 0 or -1
+    }
+    Fe8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o.l[j] = br ? a.l[j] : s.l[j];
+    return o;
+}
+
+template <bool HAS_HI>
+DEV Fe8 mont_from_u64(u32 lo, u32 hi) {
+    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
+    const u32 RR[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,       // 2^256 mod p
+                       0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    const u32 R32[8] = {0x15b8b9dau, 0x93e78865u, 0xb05ea154u, 0x16df2426u,      // 2^288 mod p
+                        0x302ab839u, 0x1271b743u, 0xec6c226eu, 0x06bc037eu};
+    u32 t[9];
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { c += (u64)lo * RR[j]; t[j] = (u32)c; c >>= 32; }
+    t[8] = (u32)c;
+    if (HAS_HI) {
+        u32 t2[9];
+        c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c += (u64)hi * R32[j]; t2[j] = (u32)c; c >>= 32; }
+        t2[8] = (u32)c;
+        c = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) { c += (u64)t[j] + t2[j]; t[j] = (u32)c; c >>= 32; }
+    }
+    const u64 th = ((u64)t[8] << 32) | t[7];
+    const u64 q = __umul64hi(th, HSW_MU);      // < 2^35
+    const u32 q_lo = (u32)q, q_hi = (u32)(q >> 32);
+    // r = (t - q*p) mod 2^256  (the true value is < 3p < 2^256)
+    Fe8 r;
+    u64 ca = 0, cb = 0;
+    long long br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        ca += (u64)q_lo * P[j];                                   // limb j of q_lo * p
+        const u32 qp = (u32)ca; ca >>= 32;
+        u64 sum = (u64)qp;
+        if (j >= 1) { cb += (u64)q_hi * P[j - 1]; sum += (u32)cb; cb >>= 32; }   // + limb j-1 of q_hi * p
+        const long long d = (long long)t[j] - (long long)sum + br;    // sum < 2^33
+        r.l[j] = (u32)d;
+        br = d >> 32;
+    }
+    r = fe_sub_p_if_geq(r);
+    r = fe_sub_p_if_geq(r);
+    return r;
+}
+// p - m for a non-zero Montgomery-form m
+DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
+    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
+    Fe8 o;
+    long long br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const long long d = (long long)P[j] - (long long)m.l[j] + br;
+        o.l[j] = (u32)d;
+        br = d >> 32;
+    }
+    return o;
+}
+
 // ------------------------------------------------------------------ emitter
-// Per-lane emission state.  Everything except `row`, `active` and `call` is
-// wave-uniform and, after inlining, a compile-time constant at every use.
-template <int T, int R = 64>
+// Emission state of one lane.  `row`, `active`, `call`, `unit` are per lane; the
+// rest is wave-uniform.  WHERE a cell goes inside the tile is not state at all:
+// it is the compile-time cursor type below, so every emitted cell is one
+// ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
+template <int T, int R, bool MONT_>
 struct Em {
-    static constexpr int ROWS = R;
+    static constexpr int TILE = T, ROWS = R;
+    static constexpr bool MONT = MONT_;
     u64 *row;          // this lane's tile row (LDS)
     const u64 *tile;   // tile base (LDS)
     u16 *d16;          // staged dense inputs of spread() calls (LDS)
     uint4 *out;        // this block's gate stream, in 16-byte pieces
-    u32 pos;           // cells currently in the tile
-    u64 neg0, neg1;    // tile positions (0..63 / 64..127) that hold a field negation (-x)
-    u32 nrows;         // units (rows) of the current phase
+    u32 nrows;         // units (rows) of the current phase-part
     u32 unit_cells;    // gate cells per unit
-    u32 cell_base;     // cell index (in block) of unit 0, tile column 0
+    u32 cell_base;     // cell index (in block) of the phase-part's first unit, cell 0
     u32 call;          // this lane's next spread-call slot (index into d16, phase-local)
     u32 unit;          // the unit (word / schedule step / round ...) this lane expands
     u32 call_first;    // block-relative index of the phase-part's first spread call
@@ -112,60 +195,90 @@ struct Em {
     bool write_gate;   // HSW_SKIP_GATE not set
 };
 
+// Compile-time emission cursor: POS = cells already in the current tile, FL =
+// tiles flushed so far in this phase, N0/N1 = tile positions (0..63 / 64..127)
+// holding a field negation.
+template <int POS, int FL, u64 N0, u64 N1>
+struct Cur {
+    static constexpr int pos = POS, fl = FL;
+    static constexpr u64 n0 = N0, n1 = N1;
+};
+using CurStart = Cur<0, 0, 0ull, 0ull>;
+
 // Transpose `ncells` tile columns out to HBM: row r goes to cells
-// [cell_base + r*unit_cells, +ncells).  Lane pairs cover one 32-byte cell
-// (low / high 16 bytes), so a wave-wide store instruction writes 1 KiB
-// contiguous when ncells*2 >= 64.
-template <int T, int R>
-DEV void flush_tile(Em<T, R> &em, u32 ncells) {
+// [cell_base + r*unit_cells + seg, +ncells).  Canonical form: lane pairs cover one
+// 32-byte cell (low / high 16 bytes), so a wave-wide store instruction writes
+// 1 KiB contiguous.  Montgomery form: one lane per cell, two 16-byte stores.
+template <class EM>
+DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
+    constexpr int T = EM::TILE;
     __syncthreads();
+    const u32 lane = threadIdx.x;
     if (em.write_gate) {
-        const u32 lane = threadIdx.x;
-        const u32 ppr = 2u * ncells;          // 16-byte pieces per row
-        const u32 total = em.nrows * ppr;
-#pragma unroll 4
-        for (u32 i = lane; i < total; i += 64) {
-            const u32 r = i / ppr;
-            const u32 q = i - r * ppr;
-            const u32 p = q >> 1, h = q & 1u;
-            const u64 v = em.tile[r * (T + 1) + p];
-            const u32 lo = (u32)v, hi = (u32)(v >> 32);
-            uint4 o;
-            o.x = h ? 0u : lo;
-            o.y = h ? 0u : hi;
-            o.z = 0u;
-            o.w = 0u;
-            if ((em.neg0 | em.neg1) != 0ull) {    // compile-time after inlining: most tiles hold no neg cell
-                const u64 mword = (T > 64 && p >= 64u) ? em.neg1 : em.neg0;
-                if (((mword >> (p & 63u)) & 1ull) && v != 0ull) {
-                    // cell holds p - x (neg gate, compression.rs:320-321), x < 2^31
-                    o.x = h ? HSW_P4 : (HSW_P0 - lo);
-                    o.y = h ? HSW_P5 : HSW_P1;
-                    o.z = h ? HSW_P6 : HSW_P2;
-                    o.w = h ? HSW_P7 : HSW_P3;
+        if constexpr (EM::MONT) {
+            const u32 total = em.nrows * ncells;
+            for (u32 i = lane; i < total; i += 64) {
+                const u32 r = i / ncells;
+                const u32 p = i - r * ncells;
+                const u64 v = em.tile[r * (T + 1) + p];
+                Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
+                if ((neg0 | neg1) != 0ull) {
+                    const u64 mword = (T > 64 && p >= 64u) ? neg1 : neg0;
+                    if (((mword >> (p & 63u)) & 1ull) && v != 0ull) m = fe_neg_nonzero(m);
                 }
+                uint4 *dst = em.out + (size_t)(em.cell_base + seg + r * em.unit_cells + p) * 2u;
+                dst[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+                dst[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
             }
-            em.out[(size_t)(em.cell_base + r * em.unit_cells + p) * 2u + h] = o;
+        } else {
+            const u32 ppr = 2u * ncells;          // 16-byte pieces per row
+            const u32 total = em.nrows * ppr;
+#pragma unroll 4
+            for (u32 i = lane; i < total; i += 64) {
+                const u32 r = i / ppr;
+                const u32 q = i - r * ppr;
+                const u32 p = q >> 1, h = q & 1u;
+                const u64 v = em.tile[r * (T + 1) + p];
+                const u32 lo = (u32)v, hi = (u32)(v >> 32);
+                uint4 o;
+                o.x = h ? 0u : lo;
+                o.y = h ? 0u : hi;
+                o.z = 0u;
+                o.w = 0u;
+                if ((neg0 | neg1) != 0ull) {          // compile-time: most tiles hold no neg cell
+                    const u64 mword = (T > 64 && p >= 64u) ? neg1 : neg0;
+                    if (((mword >> (p & 63u)) & 1ull) && v != 0ull) {
+                        // cell holds p - x (neg gate, compression.rs:320-321), x <= 0x55555555
+                        o.x = h ? HSW_P4 : (HSW_P0 - lo);
+                        o.y = h ? HSW_P5 : HSW_P1;
+                        o.z = h ? HSW_P6 : HSW_P2;
+                        o.w = h ? HSW_P7 : HSW_P3;
+                    }
+                }
+                em.out[(size_t)(em.cell_base + seg + r * em.unit_cells + p) * 2u + h] = o;
+            }
         }
     }
     __syncthreads();
-    em.cell_base += ncells;
-    em.pos = 0;
-    em.neg0 = 0;
-    em.neg1 = 0;
 }
 
-template <int T, int R>
-DEV void emit(Em<T, R> &em, u64 v) {
-    em.row[em.pos] = v;
-    if (++em.pos == (u32)T) flush_tile<T, R>(em, T);
+template <class EM, class C>
+DEV auto emit(C, EM &em, u64 v) {
+    em.row[C::pos] = v;
+    if constexpr (C::pos + 1 == EM::TILE) {
+        flush_tile(em, EM::TILE, C::fl * EM::TILE, C::n0, C::n1);
+        return Cur<0, C::fl + 1, 0ull, 0ull>{};
+    } else {
+        return Cur<C::pos + 1, C::fl, C::n0, C::n1>{};
+    }
 }
-// cell whose field value is -x (x small): stored as x plus a tile-position flag
-template <int T, int R>
-DEV void emit_neg(Em<T, R> &em, u64 x) {
-    if (em.pos < 64u) em.neg0 |= 1ull << em.pos;
-    else em.neg1 |= 1ull << (em.pos - 64u);
-    emit<T, R>(em, x);
+template <int POS, u64 N0> struct NegLo { static constexpr u64 v = N0 | (1ull << POS); };
+template <int POS, u64 N1> struct NegHi { static constexpr u64 v = N1 | (1ull << (POS - 64)); };
+// cell whose field value is -x (x small): stored as x, flagged in the cursor
+template <class EM, class C>
+DEV auto emit_neg(C, EM &em, u64 x) {
+    if constexpr (C::pos < 64) return emit(Cur<C::pos, C::fl, NegLo<C::pos, C::n0>::v, C::n1>{}, em, x);
+    else return emit(Cur<C::pos, C::fl, C::n0, NegHi<C::pos, C::n1>::v>{}, em, x);
 }
 
 // Unit expanded by this lane in a phase of n_units units split over `parts` waves
@@ -182,8 +295,8 @@ DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
 // the block split over `parts` waves, part k expands units [k*n/parts, (k+1)*n/parts)
 // (phases whose unit count is not a multiple of `parts` run on part 0 alone).
 // Returns false if this wave has nothing to do in the phase (wave-uniform).
-template <int T, int R>
-DEV bool phase_begin(Em<T, R> &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
+template <class EM>
+DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
                      u32 call_base, u32 calls_per_unit) {
     const u32 lane = threadIdx.x;
     u32 nrows, unit_lo;
@@ -197,9 +310,6 @@ DEV bool phase_begin(Em<T, R> &em, u32 part, u32 parts, u32 n_units, u32 unit_ce
     em.nrows = nrows;
     em.unit_cells = unit_cells;
     em.cell_base = phase_off + unit_lo * unit_cells;
-    em.pos = 0;
-    em.neg0 = 0;
-    em.neg1 = 0;
     em.active = lane < nrows;
     const u32 r = lane < nrows ? lane : (nrows ? nrows - 1 : 0);
     em.unit = unit_lo + r;
@@ -213,8 +323,8 @@ DEV bool phase_begin(Em<T, R> &em, u32 part, u32 parts, u32 n_units, u32 unit_ce
 // limb call n (absolute, counted from SpreadConfig.num_limb_sum = 0) lands in
 // column n % ncols at row n / ncols; buffer row 0 = row cursor0 / ncols.  Every
 // column receives one contiguous run of rows.
-template <int L, int T, int R>
-DEV void flush_chip(const Em<T, R> &em, const ExpandParams &p, u64 block_first_limb) {
+template <int L, class EM>
+DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
     constexpr int B = 16 / L;
     constexpr u32 MASK = (1u << B) - 1u;
     if (em.calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
@@ -234,107 +344,140 @@ DEV void flush_chip(const Em<T, R> &em, const ExpandParams &p, u64 block_first_l
         const u32 count = (u32)(row_hi - row_lo + 1);
         const u32 n0 = (u32)(row_lo * ncols + c - first);              // run-relative limb index of row_lo
         const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
-        for (u32 i = lane; i < 2u * count; i += 64) {
-            const u32 k = i >> 1, hpart = i & 1u;
-            const u32 n = n0 + k * (u32)ncols;
-            const u32 call = n / L, j = n % L;
-            const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
-            uint4 od, os;
-            od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
-            os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
-            cd[base + i] = od;
-            cs[base + i] = os;
+        if constexpr (EM::MONT) {
+            for (u32 k = lane; k < count; k += 64) {
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                const Fe8 md = mont_from_u64<false>(limb, 0), ms = mont_from_u64<false>(spread16(limb), 0);
+                cd[base + 2 * k] = make_uint4(md.l[0], md.l[1], md.l[2], md.l[3]);
+                cd[base + 2 * k + 1] = make_uint4(md.l[4], md.l[5], md.l[6], md.l[7]);
+                cs[base + 2 * k] = make_uint4(ms.l[0], ms.l[1], ms.l[2], ms.l[3]);
+                cs[base + 2 * k + 1] = make_uint4(ms.l[4], ms.l[5], ms.l[6], ms.l[7]);
+            }
+        } else {
+            for (u32 i = lane; i < 2u * count; i += 64) {
+                const u32 k = i >> 1, hpart = i & 1u;
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                uint4 od, os;
+                od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
+                os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
+                cd[base + i] = od;
+                cs[base + i] = os;
+            }
         }
     }
     __syncthreads();
 }
 
-template <int L, int T, int R>
-DEV void phase_end(Em<T, R> &em, const ExpandParams &p, u64 block_first_limb) {
-    if (em.pos != 0) flush_tile<T, R>(em, em.pos);
-    flush_chip<L, T, R>(em, p, block_first_limb);
+template <int L, class EM, class C>
+DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb) {
+    if constexpr (C::pos != 0) flush_tile(em, C::pos, C::fl * EM::TILE, C::n0, C::n1);
+    flush_chip<L>(em, p, block_first_limb);
 }
 
 // ---------------------------------------------------- halo2-base gate cells
-// (cell orders: DESIGN.md assumption A1)
-template <int T, int R>
-DEV void g_lw(Em<T, R> &em, u64 v) { emit<T, R>(em, v); }                 // [v]
-template <int T, int R>
-DEV u64 g_add(Em<T, R> &em, u64 a, u64 b) {                            // [a, b, 1, a+b]
-    const u64 r = a + b;
-    emit<T, R>(em, a); emit<T, R>(em, b); emit<T, R>(em, 1); emit<T, R>(em, r);
-    return r;
+// (cell orders: DESIGN.md assumption A1).  Every function takes the cursor and
+// returns the advanced cursor; runtime results come back through references.
+template <class EM, class C>
+DEV auto g_lw(C c, EM &em, u64 v) { return emit(c, em, v); }                     // [v]
+template <class EM, class C>
+DEV auto g_add(C c, EM &em, u64 a, u64 b, u64 &out) {                            // [a, b, 1, a+b]
+    out = a + b;
+    auto c1 = emit(c, em, a);
+    auto c2 = emit(c1, em, b);
+    auto c3 = emit(c2, em, 1);
+    return emit(c3, em, out);
 }
 // mul_add(a, b, c) = a*b + c -> [c, a, b, out]; `out` is passed in (computed by
 // shifts by the caller: every b is a power of two or a 3-term sum of them).
-template <int T, int R>
-DEV void g_mul_add(Em<T, R> &em, u64 a, u64 b, u64 c, u64 out) {
-    emit<T, R>(em, c); emit<T, R>(em, a); emit<T, R>(em, b); emit<T, R>(em, out);
+template <class EM, class C>
+DEV auto g_mul_add(C c, EM &em, u64 a, u64 b, u64 cc, u64 out) {
+    auto c1 = emit(c, em, cc);
+    auto c2 = emit(c1, em, a);
+    auto c3 = emit(c2, em, b);
+    return emit(c3, em, out);
 }
 
 // ------------------------------------------------------- spread.rs mirrors
 // SpreadConfig::spread (spread.rs:76-123) on a 16-bit dense value.
-template <int L, int T, int R>
-DEV u32 sc_spread(Em<T, R> &em, u32 dense) {
-    constexpr int B = 16 / L;
-    constexpr u32 MASK = (1u << B) - 1u;
-    if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced in the chip pass
-    em.call++;
-#pragma unroll
-    for (int j = 0; j < L; j++) g_lw<T, R>(em, (dense >> (B * j)) & MASK);              // :86-88
-    u32 sum = 0;
-#pragma unroll
-    for (int j = 0; j < L; j++) {                                                    // :91-98
-        const u32 limb = (dense >> (B * j)) & MASK;
-        const u32 ns = sum | (limb << (B * j));
-        g_mul_add<T, R>(em, limb, 1u << (B * j), sum, ns);
-        sum = ns;
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_lw(C c, EM &em, u32 dense) {                               // :86-88
+    if constexpr (J == L) return c;
+    else {
+        constexpr int B = 16 / L;
+        auto c1 = g_lw(c, em, (dense >> (B * J)) & ((1u << B) - 1u));
+        return spread_limbs_lw<L, J + 1>(c1, em, dense);
     }
-    u32 acc = 0;
-#pragma unroll
-    for (int j = 0; j < L; j++) {                                                    // :112-121
-        const u32 limb = (dense >> (B * j)) & MASK;
+}
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_sum(C c, EM &em, u32 dense, u32 sum) {                     // :91-98
+    if constexpr (J == L) return c;
+    else {
+        constexpr int B = 16 / L;
+        const u32 limb = (dense >> (B * J)) & ((1u << B) - 1u);
+        const u32 ns = sum | (limb << (B * J));
+        auto c1 = g_mul_add(c, em, limb, 1u << (B * J), sum, ns);
+        return spread_limbs_sum<L, J + 1>(c1, em, dense, ns);
+    }
+}
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_acc(C c, EM &em, u32 dense, u32 acc, u32 &result) {        // :112-121
+    if constexpr (J == L) { result = acc; return c; }
+    else {
+        constexpr int B = 16 / L;
+        const u32 limb = (dense >> (B * J)) & ((1u << B) - 1u);
         const u32 sl = spread16(limb);
-        g_lw<T, R>(em, sl);                                                             // spread_limb :225
-        const u32 na = acc | (sl << (2 * B * j));
-        g_mul_add<T, R>(em, sl, (u64)1 << (2 * B * j), acc, na);
-        acc = na;
+        auto c1 = g_lw(c, em, sl);                                               // spread_limb :225
+        const u32 na = acc | (sl << (2 * B * J));
+        auto c2 = g_mul_add(c1, em, sl, (u64)1 << (2 * B * J), acc, na);
+        return spread_limbs_acc<L, J + 1>(c2, em, dense, na, result);
     }
-    return acc;
+}
+template <int L, class EM, class C>
+DEV auto sc_spread(C c, EM &em, u32 dense, u32 &spread_out) {
+    if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced by flush_chip
+    em.call++;
+    auto c1 = spread_limbs_lw<L, 0>(c, em, dense);
+    auto c2 = spread_limbs_sum<L, 0>(c1, em, dense, 0u);
+    return spread_limbs_acc<L, 0>(c2, em, dense, 0u, spread_out);
 }
 
 // state_to_spread_u32 (compression.rs:215-246)
-template <int L, int T, int R>
-DEV void state_to_spread(Em<T, R> &em, u32 x) {
+template <int L, class EM, class C>
+DEV auto state_to_spread(C c, EM &em, u32 x) {
     const u32 lo = x & 0xffffu, hi = x >> 16;
-    g_lw<T, R>(em, lo);                                     // :230
-    g_lw<T, R>(em, hi);                                     // :231
-    g_mul_add<T, R>(em, hi, 1u << 16, lo, x);               // :232-237
-    sc_spread<L, T, R>(em, lo);                             // :243
-    sc_spread<L, T, R>(em, hi);                             // :244
+    u32 unused;
+    auto c1 = g_lw(c, em, lo);                               // :230
+    auto c2 = g_lw(c1, em, hi);                              // :231
+    auto c3 = g_mul_add(c2, em, hi, 1u << 16, lo, x);        // :232-237
+    auto c4 = sc_spread<L>(c3, em, lo, unused);              // :243
+    return sc_spread<L>(c4, em, hi, unused);                 // :244
 }
 
 // mod_u32 (compression.rs:266-295); x < 2^35
-template <int T, int R>
-DEV u32 mod_u32(Em<T, R> &em, u64 x) {
+template <class EM, class C>
+DEV auto mod_u32(C c, EM &em, u64 x, u32 &lo_out) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    g_lw<T, R>(em, lo);                                     // :280
-    g_lw<T, R>(em, hi);                                     // :281
-    g_mul_add<T, R>(em, hi, (u64)1 << 32, lo, x);           // :283-288
-    return lo;
+    lo_out = lo;
+    auto c1 = g_lw(c, em, lo);                               // :280
+    auto c2 = g_lw(c1, em, hi);                              // :281
+    return g_mul_add(c2, em, hi, (u64)1 << 32, lo, x);       // :283-288
 }
 
 // { spread(even); spread(odd); 2*odd_spread + even_spread } (compression.rs:344-354 etc.)
-template <int L, int T, int R>
-DEV void recheck_even_odd(Em<T, R> &em, u32 even, u32 odd) {
-    const u32 es = sc_spread<L, T, R>(em, even);
-    const u32 os = sc_spread<L, T, R>(em, odd);
-    g_mul_add<T, R>(em, 2, os, es, (u64)es + 2ull * (u64)os);
+template <int L, class EM, class C>
+DEV auto recheck_even_odd(C c, EM &em, u32 even, u32 odd) {
+    u32 es, os;
+    auto c1 = sc_spread<L>(c, em, even, es);
+    auto c2 = sc_spread<L>(c1, em, odd, os);
+    return g_mul_add(c2, em, 2, os, es, (u64)es + 2ull * (u64)os);
 }
 
-// sigma_generic (compression.rs:702-882).  S1..S3 are STARTS[1..3]; SHa/SHb/SHc
-// the three shifts of coeffs[i] (a shift of 64 = term absent: sigma_lower drops
-// the wrapped piece, :658,:685).
+// sigma_generic (compression.rs:702-882).  S1..S3 are STARTS[1..3]; C0..C3 the
+// coeffs (sigma_lower drops the wrapped piece: two terms in C0, :658,:685).
 struct SigmaUpper0 {   // :600-608
     static constexpr int S1 = 2, S2 = 13, S3 = 22;
     static constexpr u64 C0 = (1ull << 60) + (1ull << 38) + (1ull << 20);
@@ -364,108 +507,137 @@ struct SigmaLower1 {   // :681-689
     static constexpr u64 C3 = (1ull << 18) + (1ull << 4) + (1ull << 0);
 };
 
-template <class SG, int L, int T, int R>
-DEV u32 sigma_generic(Em<T, R> &em, u32 x) {
+template <class SG, int L, class EM, class C>
+DEV auto sigma_generic(C c0, EM &em, u32 x, u32 &out) {
     const u64 X = spread32(x);                               // x_spread.1 * 2^32 + x_spread.0
     // :719-734 the four pieces, spread bits [2*start, 2*end) shifted to 0
     const u64 pa = X & ((1ull << (2 * SG::S1)) - 1);
     const u64 pb = (X >> (2 * SG::S1)) & ((1ull << (2 * (SG::S2 - SG::S1))) - 1);
     const u64 pc = (X >> (2 * SG::S2)) & ((1ull << (2 * (SG::S3 - SG::S2))) - 1);
     const u64 pd = X >> (2 * SG::S3);
-    g_lw<T, R>(em, pa); g_lw<T, R>(em, pb); g_lw<T, R>(em, pc); g_lw<T, R>(em, pd);
+    auto c1 = g_lw(c0, em, pa);
+    auto c2 = g_lw(c1, em, pb);
+    auto c3 = g_lw(c2, em, pc);
+    auto c4 = g_lw(c3, em, pd);
     // :736-754 recomposition
-    u64 sum = pa, ns;
-    ns = sum + (pb << (2 * SG::S1)); g_mul_add<T, R>(em, pb, 1ull << (2 * SG::S1), sum, ns); sum = ns;
-    ns = sum + (pc << (2 * SG::S2)); g_mul_add<T, R>(em, pc, 1ull << (2 * SG::S2), sum, ns); sum = ns;
-    ns = sum + (pd << (2 * SG::S3)); g_mul_add<T, R>(em, pd, 1ull << (2 * SG::S3), sum, ns); sum = ns;
+    const u64 s1 = pa + (pb << (2 * SG::S1));
+    const u64 s2 = s1 + (pc << (2 * SG::S2));
+    const u64 s3 = s2 + (pd << (2 * SG::S3));
+    auto c5 = g_mul_add(c4, em, pb, 1ull << (2 * SG::S1), pa, s1);
+    auto c6 = g_mul_add(c5, em, pc, 1ull << (2 * SG::S2), s1, s2);
+    auto c7 = g_mul_add(c6, em, pd, 1ull << (2 * SG::S3), s2, s3);
     // :755-760 x_composed
-    g_mul_add<T, R>(em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
+    auto c8 = g_mul_add(c7, em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
     // :780-808 r_spread = sum coeff_i * piece_i  (< 2^64 by construction)
-    u64 r = 0, nr;
-    nr = r + SG::C0 * pa; g_mul_add<T, R>(em, SG::C0, pa, r, nr); r = nr;
-    nr = r + SG::C1 * pb; g_mul_add<T, R>(em, SG::C1, pb, r, nr); r = nr;
-    nr = r + SG::C2 * pc; g_mul_add<T, R>(em, SG::C2, pc, r, nr); r = nr;
-    nr = r + SG::C3 * pd; g_mul_add<T, R>(em, SG::C3, pd, r, nr); r = nr;
+    const u64 r1 = SG::C0 * pa;
+    const u64 r2 = r1 + SG::C1 * pb;
+    const u64 r3 = r2 + SG::C2 * pc;
+    const u64 r = r3 + SG::C3 * pd;
+    auto c9 = g_mul_add(c8, em, SG::C0, pa, 0, r1);
+    auto c10 = g_mul_add(c9, em, SG::C1, pb, r1, r2);
+    auto c11 = g_mul_add(c10, em, SG::C2, pc, r2, r3);
+    auto c12 = g_mul_add(c11, em, SG::C3, pd, r3, r);
     // :811-836
     const u32 r_lo = (u32)r, r_hi = (u32)(r >> 32);
-    g_lw<T, R>(em, r_lo); g_lw<T, R>(em, r_hi);
-    g_mul_add<T, R>(em, r_hi, 1ull << 32, r_lo, r);
+    auto c13 = g_lw(c12, em, r_lo);
+    auto c14 = g_lw(c13, em, r_hi);
+    auto c15 = g_mul_add(c14, em, r_hi, 1ull << 32, r_lo, r);
     // :843-846
     const u32 lo_even = even_bits(r_lo), lo_odd = even_bits(r_lo >> 1);
     const u32 hi_even = even_bits(r_hi), hi_odd = even_bits(r_hi >> 1);
-    g_lw<T, R>(em, lo_even); g_lw<T, R>(em, lo_odd);
-    g_lw<T, R>(em, hi_even); g_lw<T, R>(em, hi_odd);
-    recheck_even_odd<L, T, R>(em, lo_even, lo_odd);             // :852-862
-    recheck_even_odd<L, T, R>(em, hi_even, hi_odd);             // :863-873
-    const u32 out = (hi_even << 16) | lo_even;
-    g_mul_add<T, R>(em, hi_even, 1u << 16, lo_even, out);       // :874-879
-    return out;
+    auto c16 = g_lw(c15, em, lo_even);
+    auto c17 = g_lw(c16, em, lo_odd);
+    auto c18 = g_lw(c17, em, hi_even);
+    auto c19 = g_lw(c18, em, hi_odd);
+    auto c20 = recheck_even_odd<L>(c19, em, lo_even, lo_odd);     // :852-862
+    auto c21 = recheck_even_odd<L>(c20, em, hi_even, hi_odd);     // :863-873
+    out = (hi_even << 16) | lo_even;
+    return g_mul_add(c21, em, hi_even, 1u << 16, lo_even, out);   // :874-879
 }
 
 // ch (compression.rs:297-405); x, y, z are the dense words e, f, g
-template <int L, int T, int R>
-DEV u32 ch_gadget(Em<T, R> &em, u32 x, u32 y, u32 z) {
+template <int L, class EM, class C>
+DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
     const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
     const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
     const u32 MASK_EVEN_32 = 0x55555555u;
-    const u32 p_lo = (u32)g_add<T, R>(em, x_lo, y_lo);          // :309-313
-    const u32 p_hi = (u32)g_add<T, R>(em, x_hi, y_hi);          // :314-318
+    u64 p_lo, p_hi, q_lo, q_hi;
+    auto c1 = g_add(c0, em, x_lo, y_lo, p_lo);               // :309-313
+    auto c2 = g_add(c1, em, x_hi, y_hi, p_hi);               // :314-318
     // neg: [a, -a, 1, 0]                                       :320-321
-    emit<T, R>(em, x_lo); emit_neg<T, R>(em, x_lo); emit<T, R>(em, 1); emit<T, R>(em, 0);
-    emit<T, R>(em, x_hi); emit_neg<T, R>(em, x_hi); emit<T, R>(em, 1); emit<T, R>(em, 0);
+    auto c3 = emit(c2, em, x_lo);
+    auto c4 = emit_neg(c3, em, x_lo);
+    auto c5 = emit(c4, em, 1);
+    auto c6 = emit(c5, em, 0);
+    auto c7 = emit(c6, em, x_hi);
+    auto c8 = emit_neg(c7, em, x_hi);
+    auto c9 = emit(c8, em, 1);
+    auto c10 = emit(c9, em, 0);
     // three_add(Constant(MASK), -x, z)                         :322-335, :521-530
-    const u32 t_lo = MASK_EVEN_32 - x_lo;
-    emit<T, R>(em, MASK_EVEN_32); emit_neg<T, R>(em, x_lo); emit<T, R>(em, 1); emit<T, R>(em, t_lo);
-    const u32 q_lo = (u32)g_add<T, R>(em, t_lo, z_lo);
-    const u32 t_hi = MASK_EVEN_32 - x_hi;
-    emit<T, R>(em, MASK_EVEN_32); emit_neg<T, R>(em, x_hi); emit<T, R>(em, 1); emit<T, R>(em, t_hi);
-    const u32 q_hi = (u32)g_add<T, R>(em, t_hi, z_hi);
+    const u32 t_lo = MASK_EVEN_32 - x_lo, t_hi = MASK_EVEN_32 - x_hi;
+    auto c11 = emit(c10, em, MASK_EVEN_32);
+    auto c12 = emit_neg(c11, em, x_lo);
+    auto c13 = emit(c12, em, 1);
+    auto c14 = emit(c13, em, t_lo);
+    auto c15 = g_add(c14, em, t_lo, z_lo, q_lo);
+    auto c16 = emit(c15, em, MASK_EVEN_32);
+    auto c17 = emit_neg(c16, em, x_hi);
+    auto c18 = emit(c17, em, 1);
+    auto c19 = emit(c18, em, t_hi);
+    auto c20 = g_add(c19, em, t_hi, z_hi, q_hi);
     // :336-343 four even/odd splits before any re-check
-    const u32 p_lo_even = even_bits(p_lo), p_lo_odd = even_bits(p_lo >> 1);
-    const u32 p_hi_even = even_bits(p_hi), p_hi_odd = even_bits(p_hi >> 1);
-    const u32 q_lo_even = even_bits(q_lo), q_lo_odd = even_bits(q_lo >> 1);
-    const u32 q_hi_even = even_bits(q_hi), q_hi_odd = even_bits(q_hi >> 1);
-    g_lw<T, R>(em, p_lo_even); g_lw<T, R>(em, p_lo_odd);
-    g_lw<T, R>(em, p_hi_even); g_lw<T, R>(em, p_hi_odd);
-    g_lw<T, R>(em, q_lo_even); g_lw<T, R>(em, q_lo_odd);
-    g_lw<T, R>(em, q_hi_even); g_lw<T, R>(em, q_hi_odd);
-    recheck_even_odd<L, T, R>(em, p_lo_even, p_lo_odd);         // :344-354
-    recheck_even_odd<L, T, R>(em, p_hi_even, p_hi_odd);         // :355-365
-    recheck_even_odd<L, T, R>(em, q_lo_even, q_lo_odd);         // :366-376
-    recheck_even_odd<L, T, R>(em, q_hi_even, q_hi_odd);         // :377-387
-    const u32 out_lo = (u32)g_add<T, R>(em, p_lo_odd, q_lo_odd);    // :388-392
-    const u32 out_hi = (u32)g_add<T, R>(em, p_hi_odd, q_hi_odd);    // :393-397
-    const u32 out = (out_hi << 16) + out_lo;
-    g_mul_add<T, R>(em, out_hi, 1u << 16, out_lo, out);         // :398-403
-    return out;
+    const u32 p_lo_even = even_bits((u32)p_lo), p_lo_odd = even_bits((u32)p_lo >> 1);
+    const u32 p_hi_even = even_bits((u32)p_hi), p_hi_odd = even_bits((u32)p_hi >> 1);
+    const u32 q_lo_even = even_bits((u32)q_lo), q_lo_odd = even_bits((u32)q_lo >> 1);
+    const u32 q_hi_even = even_bits((u32)q_hi), q_hi_odd = even_bits((u32)q_hi >> 1);
+    auto c21 = g_lw(c20, em, p_lo_even);
+    auto c22 = g_lw(c21, em, p_lo_odd);
+    auto c23 = g_lw(c22, em, p_hi_even);
+    auto c24 = g_lw(c23, em, p_hi_odd);
+    auto c25 = g_lw(c24, em, q_lo_even);
+    auto c26 = g_lw(c25, em, q_lo_odd);
+    auto c27 = g_lw(c26, em, q_hi_even);
+    auto c28 = g_lw(c27, em, q_hi_odd);
+    auto c29 = recheck_even_odd<L>(c28, em, p_lo_even, p_lo_odd);     // :344-354
+    auto c30 = recheck_even_odd<L>(c29, em, p_hi_even, p_hi_odd);     // :355-365
+    auto c31 = recheck_even_odd<L>(c30, em, q_lo_even, q_lo_odd);     // :366-376
+    auto c32 = recheck_even_odd<L>(c31, em, q_hi_even, q_hi_odd);     // :377-387
+    u64 out_lo, out_hi;
+    auto c33 = g_add(c32, em, p_lo_odd, q_lo_odd, out_lo);   // :388-392
+    auto c34 = g_add(c33, em, p_hi_odd, q_hi_odd, out_hi);   // :393-397
+    out = ((u32)out_hi << 16) + (u32)out_lo;
+    return g_mul_add(c34, em, out_hi, 1u << 16, out_lo, out);    // :398-403
 }
 
 // maj (compression.rs:460-519)
-template <int L, int T, int R>
-DEV u32 maj_gadget(Em<T, R> &em, u32 x, u32 y, u32 z) {
+template <int L, class EM, class C>
+DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
     const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
     const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
-    u64 t = g_add<T, R>(em, x_lo, y_lo);
-    const u32 m_lo = (u32)g_add<T, R>(em, t, z_lo);             // :472-478
-    t = g_add<T, R>(em, x_hi, y_hi);
-    const u32 m_hi = (u32)g_add<T, R>(em, t, z_hi);             // :479-485
+    u64 t, m_lo64, m_hi64;
+    auto c1 = g_add(c0, em, x_lo, y_lo, t);
+    auto c2 = g_add(c1, em, t, z_lo, m_lo64);                // :472-478
+    auto c3 = g_add(c2, em, x_hi, y_hi, t);
+    auto c4 = g_add(c3, em, t, z_hi, m_hi64);                // :479-485
+    const u32 m_lo = (u32)m_lo64, m_hi = (u32)m_hi64;
     const u32 m_lo_even = even_bits(m_lo), m_lo_odd = even_bits(m_lo >> 1);
     const u32 m_hi_even = even_bits(m_hi), m_hi_odd = even_bits(m_hi >> 1);
-    g_lw<T, R>(em, m_lo_even); g_lw<T, R>(em, m_lo_odd);           // :486-487
-    g_lw<T, R>(em, m_hi_even); g_lw<T, R>(em, m_hi_odd);           // :488-489
-    recheck_even_odd<L, T, R>(em, m_lo_even, m_lo_odd);         // :490-500
-    recheck_even_odd<L, T, R>(em, m_hi_even, m_hi_odd);         // :501-511
-    const u32 out = (m_hi_odd << 16) | m_lo_odd;
-    g_mul_add<T, R>(em, m_hi_odd, 1u << 16, m_lo_odd, out);     // :512-517
-    return out;
+    auto c5 = g_lw(c4, em, m_lo_even);                       // :486-487
+    auto c6 = g_lw(c5, em, m_lo_odd);
+    auto c7 = g_lw(c6, em, m_hi_even);                       // :488-489
+    auto c8 = g_lw(c7, em, m_hi_odd);
+    auto c9 = recheck_even_odd<L>(c8, em, m_lo_even, m_lo_odd);      // :490-500
+    auto c10 = recheck_even_odd<L>(c9, em, m_hi_even, m_hi_odd);     // :501-511
+    out = (m_hi_odd << 16) | m_lo_odd;
+    return g_mul_add(c10, em, m_hi_odd, 1u << 16, m_lo_odd, out);    // :512-517
 }
 
 // --------------------------------------------------------------- the kernel
 // T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
 // units one wave expands per phase; a block needs parts >= 64/R waves.
-template <int L, int T, int R>
+template <int L, int T, int R, bool MONT>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     using LY = Lay<L>;
     static_assert(R * (T + 1) * 8 >= 800, "tile must be able to hold the chain seeds");
@@ -538,7 +710,8 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
     __syncthreads();           // seeds are in registers: the tile may now overwrite them
 
-    Em<T, R> em;
+    using EM = Em<T, R, MONT>;
+    EM em;
     em.tile = s_tile;
     em.row = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 1);   // lanes >= R never flush: scratch row
     em.d16 = s_d16;
@@ -547,73 +720,77 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
 
     // ---- words: compression.rs:31-47, 16 units of 4 mul_add ----------------
-    if (phase_begin<T, R>(em, part, parts, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
-        const u32 word = seed_word;
-        u32 sum = 0;
-#pragma unroll
-        for (int idx = 0; idx < 4; idx++) {                  // bytes[3 - idx] * 2^(8 idx) + sum
-            const u32 byte = (word >> (8 * idx)) & 0xffu;
-            const u32 ns = sum | (byte << (8 * idx));
-            g_mul_add<T, R>(em, byte, 1u << (8 * idx), sum, ns);
-            sum = ns;
-        }
-        phase_end<L, T, R>(em, p, blk_limb0);
+    if (phase_begin(em, part, parts, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
+        const u32 word = seed_word;                          // bytes[3 - idx] * 2^(8 idx) + sum
+        const u32 b0 = word & 0xffu, b1 = (word >> 8) & 0xffu, b2 = (word >> 16) & 0xffu, b3 = word >> 24;
+        const u32 s0 = b0, s1 = s0 | (b1 << 8), s2 = s1 | (b2 << 16);
+        auto c1 = g_mul_add(CurStart{}, em, b0, 1u, 0u, s0);
+        auto c2 = g_mul_add(c1, em, b1, 1u << 8, s0, s1);
+        auto c3 = g_mul_add(c2, em, b2, 1u << 16, s1, s2);
+        auto c4 = g_mul_add(c3, em, b3, 1u << 24, s2, word);
+        phase_end<L>(c4, em, p, blk_limb0);
     }
 
     // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
-    if (phase_begin<T, R>(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
-        state_to_spread<L, T, R>(em, seed_word);
-        phase_end<L, T, R>(em, p, blk_limb0);
+    if (phase_begin(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
+        auto c1 = state_to_spread<L>(CurStart{}, em, seed_word);
+        phase_end<L>(c1, em, p, blk_limb0);
     }
 
     // ---- schedule: compression.rs:57-96, 48 units --------------------------
-    if (phase_begin<T, R>(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED)) {
+    if (phase_begin(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED)) {
         const u32 w2 = seed_w2, w15 = seed_w15, w7 = seed_w7, w16 = seed_w16;   // W[idx-2], [idx-15], [idx-7], [idx-16]
-        const u32 term1 = sigma_generic<SigmaLower1, L, T, R>(em, w2);      // :60
-        const u32 term3 = sigma_generic<SigmaLower0, L, T, R>(em, w15);     // :61
-        u64 sum = g_add<T, R>(em, term1, w7);                               // :65-69
-        sum = g_add<T, R>(em, sum, term3);                                  // :70-74
-        sum = g_add<T, R>(em, sum, w16);                                    // :75-79
-        const u32 new_w = mod_u32<T, R>(em, sum);                           // :80
-        state_to_spread<L, T, R>(em, new_w);                                // :90
-        phase_end<L, T, R>(em, p, blk_limb0);
+        u32 term1, term3, new_w;
+        u64 sum;
+        auto c1 = sigma_generic<SigmaLower1, L>(CurStart{}, em, w2, term1);    // :60
+        auto c2 = sigma_generic<SigmaLower0, L>(c1, em, w15, term3);           // :61
+        auto c3 = g_add(c2, em, term1, w7, sum);                               // :65-69
+        auto c4 = g_add(c3, em, sum, term3, sum);                              // :70-74
+        auto c5 = g_add(c4, em, sum, w16, sum);                                // :75-79
+        auto c6 = mod_u32(c5, em, sum, new_w);                                 // :80
+        auto c7 = state_to_spread<L>(c6, em, new_w);                           // :90
+        phase_end<L>(c7, em, p, blk_limb0);
     }
 
     // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
-    if (phase_begin<T, R>(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
-        state_to_spread<L, T, R>(em, seed_state);
-        phase_end<L, T, R>(em, p, blk_limb0);
+    if (phase_begin(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
+        auto c1 = state_to_spread<L>(CurStart{}, em, seed_state);
+        phase_end<L>(c1, em, p, blk_limb0);
     }
 
     // ---- 64 rounds: compression.rs:125-196 ---------------------------------
-    if (phase_begin<T, R>(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND)) {
+    if (phase_begin(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND)) {
         const u32 a = seed_a, b = seed_b, c = seed_c, d = seed_d;
         const u32 e = seed_e, f = seed_f, g = seed_g, h = seed_h;
-        const u32 sig1 = sigma_generic<SigmaUpper1, L, T, R>(em, e);        // :130
-        const u32 chv = ch_gadget<L, T, R>(em, e, f, g);                    // :131
-        u64 s = g_add<T, R>(em, h, sig1);                                   // :138-142
-        s = g_add<T, R>(em, s, chv);                                        // :143-147
-        s = g_add<T, R>(em, s, seed_k);                                     // :148-152
-        s = g_add<T, R>(em, s, seed_wr);                                    // :153-157
-        const u32 t1 = mod_u32<T, R>(em, s);                                // :158
-        const u32 sig0 = sigma_generic<SigmaUpper0, L, T, R>(em, a);        // :164
-        const u32 mjv = maj_gadget<L, T, R>(em, a, b, c);                   // :165
-        s = g_add<T, R>(em, sig0, mjv);                                     // :166-170
-        const u32 t2 = mod_u32<T, R>(em, s);                                // :171
-        s = g_add<T, R>(em, d, t1);                                         // :181
-        const u32 e_new = mod_u32<T, R>(em, s);                             // :182
-        state_to_spread<L, T, R>(em, e_new);                                // :184
-        s = g_add<T, R>(em, t1, t2);                                        // :192
-        const u32 a_new = mod_u32<T, R>(em, s);                             // :193
-        state_to_spread<L, T, R>(em, a_new);                                // :195
-        phase_end<L, T, R>(em, p, blk_limb0);
+        u32 sig1, chv, t1, sig0, mjv, t2, e_new, a_new;
+        u64 s;
+        auto c1 = sigma_generic<SigmaUpper1, L>(CurStart{}, em, e, sig1);      // :130
+        auto c2 = ch_gadget<L>(c1, em, e, f, g, chv);                          // :131
+        auto c3 = g_add(c2, em, h, sig1, s);                                   // :138-142
+        auto c4 = g_add(c3, em, s, chv, s);                                    // :143-147
+        auto c5 = g_add(c4, em, s, seed_k, s);                                 // :148-152
+        auto c6 = g_add(c5, em, s, seed_wr, s);                                // :153-157
+        auto c7 = mod_u32(c6, em, s, t1);                                      // :158
+        auto c8 = sigma_generic<SigmaUpper0, L>(c7, em, a, sig0);              // :164
+        auto c9 = maj_gadget<L>(c8, em, a, b, c, mjv);                         // :165
+        auto c10 = g_add(c9, em, sig0, mjv, s);                                // :166-170
+        auto c11 = mod_u32(c10, em, s, t2);                                    // :171
+        auto c12 = g_add(c11, em, d, t1, s);                                   // :181
+        auto c13 = mod_u32(c12, em, s, e_new);                                 // :182
+        auto c14 = state_to_spread<L>(c13, em, e_new);                         // :184
+        auto c15 = g_add(c14, em, t1, t2, s);                                  // :192
+        auto c16 = mod_u32(c15, em, s, a_new);                                 // :193
+        auto c17 = state_to_spread<L>(c16, em, a_new);                         // :195
+        phase_end<L>(c17, em, p, blk_limb0);
     }
 
     // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
-    if (phase_begin<T, R>(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0)) {
-        const u64 s = g_add<T, R>(em, seed_fx, seed_fy);
-        mod_u32<T, R>(em, s);
-        phase_end<L, T, R>(em, p, blk_limb0);
+    if (phase_begin(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0)) {
+        u64 s;
+        u32 lo;
+        auto c1 = g_add(CurStart{}, em, seed_fx, seed_fy, s);
+        auto c2 = mod_u32(c1, em, s, lo);
+        phase_end<L>(c2, em, p, blk_limb0);
     }
 }
 
@@ -692,8 +869,11 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
 template <int L, int T, int R>
 static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
     if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
-    hipLaunchKernelGGL((hsw_expand_kernel<L, T, R>), dim3((unsigned)(p.n_blocks * p.parts)), dim3(64), 0,
-                       stream, p);
+    const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
+    if (p.flags & HSW_K_MONTGOMERY)
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, true>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, false>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -675,6 +675,16 @@ int oracle_digest(oracle_ctx *c, const uint8_t *input, size_t input_byte_size,
     return c->failed ? 1 : 0;
 }
 
+/* Canonical -> Montgomery form (halo2curves bn256::Fr in-memory representation:
+ * x * 2^256 mod p), by generic 512-bit multiply + bit-serial reduction --
+ * deliberately NOT the Barrett shortcut the kernel uses. */
+void oracle_to_montgomery(ofe_t *cells, size_t n) {
+    /* R = 2^256 mod p, derived here rather than hard-coded: double 1 mod p 256 times */
+    ofe_t r = fe_u64(1);
+    for (int i = 0; i < 256; i++) r = fe_add(&r, &r);
+    for (size_t i = 0; i < n; i++) cells[i] = fe_mul_slow(&cells[i], &r);
+}
+
 int oracle_measure_shape(int num_bits_lookup, int num_advice_columns,
                          uint64_t *gate_cells_per_block, uint64_t *limb_calls_per_block) {
     oracle_ctx *c = oracle_create(num_bits_lookup, num_advice_columns, 1);

@@ -126,6 +126,10 @@ void oracle_plain_compress(uint32_t state[8], const uint8_t block[64]);
 /* SpreadConfig::load table row i (spread.rs:165-194): (i, spread(i)). */
 uint64_t oracle_spread_table_entry(uint32_t i);
 
+/* In-place canonical -> Montgomery form (x * 2^256 mod p), the in-memory form of
+ * halo2curves' Fr; checks HSW_REPR_MONTGOMERY output. */
+void oracle_to_montgomery(ofe_t *cells, size_t n);
+
 /* Shape numbers derived by *running* one block (not from formulas). */
 int oracle_measure_shape(int num_bits_lookup, int num_advice_columns,
                          uint64_t *gate_cells_per_block,

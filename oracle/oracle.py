@@ -71,6 +71,7 @@ def lib():
         L.oracle_plain_compress.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_spread_table_entry.restype = C.c_uint64
         L.oracle_spread_table_entry.argtypes = [C.c_uint32]
+        L.oracle_to_montgomery.argtypes = [C.c_void_p, C.c_size_t]
         L.oracle_measure_shape.restype = C.c_int
         L.oracle_measure_shape.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
@@ -200,6 +201,13 @@ def gate_tape(num_bits_lookup=8, num_advice_columns=2):
     o.L.oracle_set_kinds(o.h, None, 0)
     o._check()
     return kinds
+
+
+def to_montgomery(cells):
+    """Copy of a (..., 4) uint64 cell array converted to Montgomery form."""
+    a = np.ascontiguousarray(cells, dtype=np.uint64).copy()
+    lib().oracle_to_montgomery(a.ctypes.data, a.size // 4)
+    return a
 
 
 def plain_compress(state, block):

@@ -215,3 +215,28 @@ def test_argument_errors(engine_factory, hsw):
     # zero blocks is a no-op
     assert lib.hsw_witness_blocks(eng.h, None, None, 0, 0, None, None, None, 0, None, 0) == N.HSW_OK
     assert b"" != lib.hsw_last_error(eng.h)
+
+
+@pytest.mark.parametrize("bits,ncols,cursor0", [(8, 2, 0), (16, 1, 0), (4, 3, 5), (8, 2, 4121)])
+def test_montgomery_representation(engine_factory, oracle, hsw, bits, ncols, cursor0):
+    """HSW_REPR_MONTGOMERY: every cell is x * 2^256 mod p (halo2curves' in-memory
+    Fr).  Checked against the oracle's canonical streams converted by a generic
+    512-bit multiply-reduce (not the kernel's Barrett shortcut)."""
+    eng = engine_factory(bits, ncols)
+    blocks, pre = _rand_inputs(3, 555 + bits)
+    blocks[0] = 0
+    pre[0] = 0                    # neg(0) = 0 cells, tiny values
+    blocks[1] = 0xFF
+    pre[1] = 0xFFFFFFFF           # r_spread = 2^64 - 1: the widest non-negated cell
+    ref = oracle.Oracle(bits, ncols, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
+    got = _run_gpu(eng, blocks, pre, cursor0=cursor0, flags=hsw.HSW_REPR_MONTGOMERY)
+    exp_gate = oracle.to_montgomery(ref["gate"])
+    g = got["gate"].view(np.uint64)
+    if not np.array_equal(g, exp_gate):
+        bad = np.nonzero((g != exp_gate).any(axis=1))[0]
+        raise AssertionError("montgomery gate differs at %d cells, first %d: gpu %s exp %s (canonical %s)" % (
+            len(bad), bad[0], g[bad[0]], exp_gate[bad[0]], ref["gate"][bad[0]]))
+    # chip columns: untouched neighbour cells stay zero in both (0 -> 0 in Montgomery form too)
+    assert np.array_equal(got["dense"].view(np.uint64), oracle.to_montgomery(ref["dense"]))
+    assert np.array_equal(got["spread"].view(np.uint64), oracle.to_montgomery(ref["spread"]))
+    assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])

@@ -149,3 +149,17 @@ def test_all_table_widths_selfcheck(oracle, bits):
     g, lc = oracle.measure_shape(bits, 2)
     L = 16 // bits
     assert g == 25108 + 2060 * 10 * L and lc == 2060 * L
+
+
+def test_to_montgomery_matches_bigint(oracle):
+    """x -> x * 2^256 mod p (halo2curves Fr memory form), vs Python integers."""
+    P = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    R = (1 << 256) % P
+    assert R == 0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb   # halo2curves bn256 fr.rs R
+    rng = np.random.default_rng(3)
+    vals = [0, 1, 2, 255, 0x55555555, 0xFFFFFFFF, 1 << 32, (1 << 64) - 1, P - 1, P - 0x55555555]
+    vals += [int(rng.integers(0, 2**63)) << int(rng.integers(0, 2)) for _ in range(50)]
+    a = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+    m = oracle.to_montgomery(a)
+    for v, row in zip(vals, m):
+        assert sum(int(row[k]) << (64 * k) for k in range(4)) == (v * R) % P

@@ -6,7 +6,7 @@ import numpy as np, torch
 n = int(sys.argv[1]); reps = int(sys.argv[2])
 variants = []
 for spec in sys.argv[3:]:
-    path, parts, tile = (spec.split(":") + ["", ""])[:3]
+    path, parts, tile, vflags = (spec.split(":") + ["", "", ""])[:4]
     L = C.CDLL(path)
     L.hsw_engine_create.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.hsw_witness_blocks.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_uint64] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_uint32]
@@ -20,7 +20,7 @@ for spec in sys.argv[3:]:
         assert L.hsw_engine_set_option(h, b"parts", int(parts)) == 0
         if tile:
             assert L.hsw_engine_set_option(h, b"tile", int(tile)) == 0
-    variants.append((spec, L, h))
+    variants.append((spec, L, h, int(vflags or 0)))
 rng = np.random.default_rng(0xC3)
 blocks = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
 pre = torch.from_numpy(np.tile(np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32).view(np.int32), (n, 1))).cuda()
@@ -29,17 +29,17 @@ gate = torch.empty((n * G, 4), dtype=torch.int64, device="cuda")
 dense = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
 spread = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
 nxt = torch.empty((n, 8), dtype=torch.int32, device="cuda")
-def run(L, h):
-    rc = L.hsw_witness_blocks(h, blocks.data_ptr(), pre.data_ptr(), n, 0, gate.data_ptr(), dense.data_ptr(), spread.data_ptr(), 2060 * n, nxt.data_ptr(), 0)
+def run(L, h, fl=0):
+    rc = L.hsw_witness_blocks(h, blocks.data_ptr(), pre.data_ptr(), n, 0, gate.data_ptr(), dense.data_ptr(), spread.data_ptr(), 2060 * n, nxt.data_ptr(), fl)
     assert rc == 0, rc
     ms = C.c_float(); assert L.hsw_last_kernel_ms(h, C.byref(ms)) == 0
     return ms.value
 for _ in range(3):
-    for _, L, h in variants: run(L, h)
-times = {spec: [] for spec, _, _ in variants}
+    for _, L, h, fl in variants: run(L, h, fl)
+times = {spec: [] for spec, _, _, _ in variants}
 for _ in range(reps):
-    for spec, L, h in variants:
-        times[spec].append(run(L, h))
+    for spec, L, h, fl in variants:
+        times[spec].append(run(L, h, fl))
 L0, h0 = variants[-1][1], variants[-1][2]
 if hasattr(L0, "hsw_fill_calibrate"):
     L0.hsw_fill_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
