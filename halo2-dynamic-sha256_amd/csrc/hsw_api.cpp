@@ -21,7 +21,7 @@ struct hsw_engine {
     hsw_shape shape{};
     int limbs = 2;
     int parts = 0;             // waves per block; 0 = choose from the batch size
-    int tile = 32;             // tile width in cells: 32, 64 or 128
+    int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
     bool timing = false;
     bool timed = false;        // ev0/ev1 bracket a launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -67,14 +67,23 @@ int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSucc
     return status;
 }
 
-// Waves per block.  A block is 64 + 48 + ... independent units; one wave can
-// expand all of them (lane = unit), or the units can be dealt to 2..16 waves.
-// Large batches fill the chip with one wave per block; small ones (e.g. the
-// 16-block message of BASELINE configs[1]) need the split to occupy 256 CUs.
-int choose_parts(const hsw_engine *e, size_t n_blocks) {
-    const int min_parts = e->tile / 32;           // a T-cell tile has 64*32/T rows
+// Tile shape and waves per block (tuning only; results never change).
+//  * tile: cells per contiguous run of one unit.  Measured on MI355X (tools/ab.py,
+//    interleaved in one process, 4,096 blocks): canonical output is ~3 % faster
+//    with 64-cell tiles and 4 waves per block than with 32-cell tiles and one
+//    wave; Montgomery output (ALU-heavier write-out) prefers 32-cell tiles.
+//  * parts: a block is 64 + 48 + ... independent units; one wave can expand all
+//    of them (lane = unit) or they can be dealt to 2..16 waves.  Small batches
+//    (e.g. the 16-block message of BASELINE configs[1]) need the split to
+//    occupy 256 CUs.
+int choose_tile(const hsw_engine *e, bool mont) {
+    if (e->tile > 0) return (e->limbs == 2) ? e->tile : 32;     // wide tiles are built for 8-bit tables only
+    return (e->limbs == 2 && !mont) ? 64 : 32;
+}
+int choose_parts(const hsw_engine *e, size_t n_blocks, int tile) {
+    const int min_parts = tile / 32;              // a T-cell tile has 64*32/T rows
     if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
-    int parts = min_parts;
+    int parts = tile == 64 ? 4 : min_parts;
     while (parts < 16 && n_blocks * (size_t)parts < 2048) parts *= 2;
     return parts;
 }
@@ -207,8 +216,8 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         return HSW_OK;
     }
     if (std::strcmp(name, "tile") == 0) {
-        if (value != 32 && value != 64 && value != 128)
-            return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 32, 64 or 128");
+        if (value != 0 && value != 32 && value != 64 && value != 128)
+            return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 0 (auto), 32, 64 or 128");
         e->tile = (int)value;
         return HSW_OK;
     }
@@ -284,7 +293,8 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         p.ncols = e->shape.num_advice_columns;
         p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP) |
                   ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY ? hsw::HSW_K_MONTGOMERY : 0u);
-        p.parts = (uint32_t)choose_parts(e, n_blocks);
+        const int tile = choose_tile(e, (flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY);
+        p.parts = (uint32_t)choose_parts(e, n_blocks, tile);
         if (done != 0) {
             // later chunks: keep buffer row 0 fixed by pre-offsetting the column
             // base instead of the cursor origin
@@ -297,7 +307,7 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
                 p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES;
             }
         }
-        he = hsw::launch_expand(p, e->limbs, e->tile, e->stream);
+        he = hsw::launch_expand(p, e->limbs, tile, e->stream);
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_expand_kernel", he);
     }
     if (e->timing) {

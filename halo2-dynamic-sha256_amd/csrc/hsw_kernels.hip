@@ -1,27 +1,33 @@
 // hsw_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the SHA-256 witness engine.
 //
-// One 64-lane wavefront per message block (workgroup = one wave).
+// One 64-lane wavefront per work item (workgroup = one wave); a block is one
+// work item, or is dealt to 2..16 of them (`parts`).
 //
-//  chain phase   the plain SHA-256 recurrence of the block (W[0..63], and the
-//                a/e values born in every round) is computed once, wave-uniform,
-//                and staged in LDS (sW, sA, sE).  From these seeds every unit of
-//                the gadget (a schedule step, a round, ...) is independent.
+//  chain phase   the plain SHA-256 recurrence of the block (W[0..63] and the a/e
+//                value born in every round) is computed once, wave-uniform, and
+//                staged in LDS; every lane then pulls the seeds of ITS units
+//                into registers.  From these seeds every unit of the gadget (a
+//                schedule step, a round, ...) is independent.
 //  expand phase  lane = unit.  Every lane runs the same straight-line program --
 //                the reference's gate-call sequence for that unit
 //                (compression.rs:57-96 for a schedule step, :125-196 for a
-//                round) -- and appends each gate cell to its own row of a
-//                [64][T] LDS tile (64-bit values; spread/dense conversions are
-//                shift/mask bit interleaves, no table reads).  When a tile is
-//                full the wave transposes it out: for every row, 64 lanes store
-//                64 consecutive 16-byte pieces (= T/… cells x 32 B), i.e. one
-//                fully contiguous 1 KiB global_store_dwordx4 per instruction.
-//                Emission offsets and flush points are compile-time constants
-//                after inlining, so an emitted cell is a single ds_write_b64
-//                with an immediate offset.
-//  chip pass     the 16-bit dense input of every SpreadConfig::spread call is
-//                staged in LDS (2,060 per block); at the end of the block the
-//                chip columns denses[c] / spreads[c] (spread.rs:196-233) are
-//                written as contiguous column runs.
+//                round) -- and appends each gate cell to its own row of an
+//                [R][T] LDS tile of 64-bit values.  WHERE a cell goes is a
+//                compile-time cursor type (Cur<POS, FLUSHES, NEG0, NEG1>)
+//                threaded through every gate function, so an emitted cell is
+//                one ds_write_b64 at an immediate offset and each flush point
+//                is an `if constexpr`.  Spread/dense conversions are shift/mask
+//                bit interleaves, no table reads.
+//  write-out     when a tile is full the wave transposes it to HBM: for every
+//                row, lanes store consecutive 16-byte pieces, i.e. each
+//                global_store_dwordx4 wave-instruction writes 1 KiB contiguous
+//                (canonical form).  Montgomery form (x * 2^256 mod p,
+//                halo2curves' in-memory Fr) does one 64x256-bit
+//                multiply + Barrett reduce per cell, one lane per cell.
+//  chip columns  the 16-bit dense input of every SpreadConfig::spread call is
+//                staged in LDS; at the end of each phase the chip columns
+//                denses[c] / spreads[c] (spread.rs:196-233) receive one
+//                contiguous run of rows per column.
 //
 // Pure 32/64-bit integer work, write-streaming: the bound is HBM write
 // bandwidth (DESIGN.md "Roofline").  No MFMA.

@@ -28,7 +28,7 @@
  *   next states  8 u32 words per block (compression.rs:197-212).
  * One cell = 32 bytes = one BN254 scalar-field element, 4 little-endian 64-bit
  * limbs, canonical (HSW_REPR_CANONICAL) or Montgomery (HSW_REPR_MONTGOMERY,
- * the in-memory form of halo2curves' Fr) form.
+ * the in-memory form of halo2curves' Fr) form; both are built.
  *
  * All entry points return an int status (HSW_OK = 0); nothing unwinds across
  * the ABI.  Shape violations that the reference would `assert!`/`debug_assert!`
@@ -233,7 +233,7 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
 
 /* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
  * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
- * contiguous run of one unit, 32 (default), 64 or 128. */
+ * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128. */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 
 const char *hsw_strerror(int status);

@@ -104,3 +104,17 @@ def test_gadget_errors(engine_factory, hsw):
     assert cfg.view().cur_hash_idx == 0 and cfg.view().blocks_done == 0   # nothing committed
     assert cfg.digest(b"abc").output_bytes == hashlib.sha256(b"abc").digest()
     cfg.close()
+
+
+def test_gadget_montgomery_repr(engine_factory, hsw, oracle):
+    """hsw_gadget_set_repr(HSW_REPR_MONTGOMERY): same digests, cells in halo2curves' memory form."""
+    eng = engine_factory(8, 2)
+    cfg = hsw.Sha256DynamicConfig(eng, [128], True)
+    cfg.set_repr(hsw.HSW_REPR_MONTGOMERY)
+    r = cfg.digest(b"abc")
+    assert r.output_bytes == hashlib.sha256(b"abc").digest()
+    ref = oracle.Oracle(8, 2, check=True).digest(b"abc", 128, want_streams=True)
+    st = cfg.streams()
+    assert np.array_equal(st["gate"], oracle.to_montgomery(ref["gate"]))
+    assert np.array_equal(st["dense"], oracle.to_montgomery(ref["dense"]))
+    cfg.close()

@@ -240,3 +240,41 @@ def test_montgomery_representation(engine_factory, oracle, hsw, bits, ncols, cur
     assert np.array_equal(got["dense"].view(np.uint64), oracle.to_montgomery(ref["dense"]))
     assert np.array_equal(got["spread"].view(np.uint64), oracle.to_montgomery(ref["spread"]))
     assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])
+
+
+@pytest.mark.parametrize("tile,parts", [(32, 1), (32, 2), (32, 4), (32, 8), (32, 16), (64, 2), (64, 4), (64, 16),
+                                        (128, 4), (128, 8), (128, 16), (0, 0)])
+@pytest.mark.parametrize("mont", [False, True])
+def test_every_tile_shape_and_split_gives_identical_streams(engine_factory, oracle, hsw, tile, parts, mont):
+    """Tuning knobs never change results: every (tile, waves-per-block) combination,
+    canonical and Montgomery, against the oracle (cursor 3 with 2 columns: split rows)."""
+    eng = engine_factory(8, 2)
+    eng.set_option("tile", tile)
+    eng.set_option("parts", parts)
+    try:
+        blocks, pre = _rand_inputs(3, 1234)
+        ref = oracle.Oracle(8, 2, check=True).witness_blocks(blocks, pre, cursor0=3)
+        got = _run_gpu(eng, blocks, pre, cursor0=3, flags=hsw.HSW_REPR_MONTGOMERY if mont else 0)
+        conv = oracle.to_montgomery if mont else (lambda x: x)
+        assert np.array_equal(got["gate"].view(np.uint64), conv(ref["gate"]))
+        assert np.array_equal(got["dense"].view(np.uint64), conv(ref["dense"]))
+        assert np.array_equal(got["spread"].view(np.uint64), conv(ref["spread"]))
+        assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])
+    finally:
+        eng.set_option("tile", 0)
+        eng.set_option("parts", 0)
+
+
+def test_huge_cursor_and_second_stream(hsw, oracle):
+    """num_limb_sum beyond 2^32 (u64 row arithmetic) on an engine bound to a
+    non-default HIP stream."""
+    import torch
+    st = torch.cuda.Stream()
+    eng = hsw.WitnessEngine(0, 8, 3, stream=st)
+    blocks, pre = _rand_inputs(2, 9)
+    cursor0 = (1 << 40) + 2
+    ref = oracle.Oracle(8, 3, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
+    with torch.cuda.stream(st):
+        got = _run_gpu(eng, blocks, pre, cursor0=cursor0)
+    _assert_same(got, ref)
+    eng.close()
