@@ -248,6 +248,33 @@ def main():
         assert b"".join(int(x).to_bytes(4, "big") for x in last) == hashlib.sha256(m).digest()
         extra["config1_1KiB_message_16_blocks"] = {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt}
 
+    if not args.no_extra and rank == 0:
+        # BASELINE configs[4] needs the Rust prover (create_proof at k=20): not runnable here.
+        # SURVEY 8d substitute: the witness columns of a k=20-sized circuit (~120 blocks at 9
+        # advice columns) delivered to HOST memory, where a CPU MSM/FFT prover would read them:
+        # pipelined kernel || D2H into pinned buffers.  PCIe-bound by construction.
+        try:
+            nb = 120
+            t1 = time.perf_counter()
+            hostout = eng.witness_blocks_host(blocks_h[:nb], pre_h[:nb], cursor0=0, pinned=True)
+            t_first = time.perf_counter() - t1
+            keep = hostout          # reuse the pinned buffers: time steady-state calls through the C ABI
+            reps = 5
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                rc = eng.lib.hsw_witness_blocks_host(
+                    eng.h, blocks_h[:nb].ctypes.data, pre_h[:nb].ctypes.data, nb, 0, keep["gate"].ctypes.data,
+                    keep["dense"].ctypes.data, keep["spread"].ctypes.data, keep["dense"].shape[1], None, 0)
+                assert rc == 0
+            dt = (time.perf_counter() - t1) / reps
+            extra["config4_substitute_k20_witness_to_host"] = {
+                "blocks": nb, "ms": dt * 1e3, "blocks_per_s": nb / dt, "host_GBps": nb * alg_bytes / dt / 1e9,
+                "first_call_ms": t_first * 1e3,
+                "note": "create_proof itself is not runnable (no Rust toolchain); pinned host buffers, PCIe Gen5 x16 spec 63 GB/s"}
+            del hostout, keep
+        except Exception as ex:
+            extra["config4_substitute_k20_witness_to_host"] = {"error": repr(ex)}
+
     if distributed and not args.no_extra:
         # north_star's all-gather of witness columns over xGMI (RCCL), on a bounded
         # shard: 256 blocks (543 MB of gate cells) per rank.  Reported separately,

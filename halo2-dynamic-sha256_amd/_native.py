@@ -24,6 +24,7 @@ HSW_REPR_CANONICAL = 0
 HSW_REPR_MONTGOMERY = 1
 HSW_SKIP_GATE = 2
 HSW_SKIP_CHIP = 4
+HSW_HOST_REGISTER = 8
 HSW_CELL_BYTES = 32
 
 
@@ -65,7 +66,7 @@ SYMBOLS = (
     "hsw_last_error", "hsw_abi_version", "hsw_engine_set_option", "hsw_fill_calibrate",
     "hsw_engine_stream", "hsw_digest_prepare", "hsw_gadget_create", "hsw_gadget_destroy",
     "hsw_gadget_digest", "hsw_gadget_digest_batch", "hsw_gadget_streams", "hsw_gadget_input_bytes",
-    "hsw_gadget_set_repr", "hsw_download",
+    "hsw_gadget_set_repr", "hsw_download", "hsw_host_alloc", "hsw_host_free",
 )
 
 
@@ -145,6 +146,10 @@ def lib():
         L.hsw_gadget_streams.argtypes = [vp, C.POINTER(GadgetView)]
         L.hsw_gadget_input_bytes.restype = C.c_int
         L.hsw_gadget_input_bytes.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hsw_host_alloc.restype = C.c_int
+        L.hsw_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.hsw_host_free.restype = None
+        L.hsw_host_free.argtypes = [vp]
         L.hsw_download.restype = C.c_int
         L.hsw_download.argtypes = [vp, vp, vp, C.c_size_t]
         L.hsw_gadget_set_repr.restype = C.c_int

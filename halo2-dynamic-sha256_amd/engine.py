@@ -11,6 +11,19 @@ import ctypes as C
 from . import _native as N
 
 
+class _Pinned:
+    """Owner of one hsw_host_alloc allocation."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.hsw_host_free(self.ptr)
+        except Exception:
+            pass
+
+
 class WitnessEngine:
     """One hsw_engine bound to (device, stream).
 
@@ -91,6 +104,35 @@ class WitnessEngine:
             dense.shape[1] if dense is not None else 0,
             nxt.data_ptr() if nxt is not None else None, flags)
         self._ok(rc)
+        return out
+
+    def witness_blocks_host(self, blocks, pre_states, cursor0=0, flags=0, pinned=True):
+        """Host delivery (hsw_witness_blocks_host): numpy in, numpy out.  With
+        pinned=True the output arrays live in page-locked memory from
+        hsw_host_alloc (freed when the returned dict's "_keep" is dropped)."""
+        import numpy as np
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 64)
+        pre_states = np.ascontiguousarray(pre_states, dtype=np.uint32).reshape(-1, 8)
+        n = blocks.shape[0]
+        rows = self.chip_rows(cursor0, n)
+        shapes = dict(gate=(n * self.G, 4), dense=(self.ncols, rows, 4), spread=(self.ncols, rows, 4))
+        out, keep = {}, []
+        for k, shp in shapes.items():
+            nbytes = int(np.prod(shp)) * 8
+            if pinned:
+                p = C.c_void_p()
+                self._ok(self.lib.hsw_host_alloc(nbytes, C.byref(p)))
+                keep.append(_Pinned(self.lib, p))
+                buf = (C.c_uint8 * nbytes).from_address(p.value)
+                out[k] = np.frombuffer(buf, dtype=np.uint64).reshape(shp)
+            else:
+                out[k] = np.zeros(shp, dtype=np.uint64)
+        nxt = np.zeros((n, 8), dtype=np.uint32)
+        self._ok(self.lib.hsw_witness_blocks_host(
+            self.h, blocks.ctypes.data, pre_states.ctypes.data, n, cursor0, out["gate"].ctypes.data,
+            out["dense"].ctypes.data, out["spread"].ctypes.data, rows, nxt.ctypes.data, flags))
+        out["next_states"] = nxt
+        out["_keep"] = keep
         return out
 
     def sha256_chain(self, blocks, n_messages, blocks_per_message, init_states=None):

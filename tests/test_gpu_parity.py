@@ -278,3 +278,17 @@ def test_huge_cursor_and_second_stream(hsw, oracle):
         got = _run_gpu(eng, blocks, pre, cursor0=cursor0)
     _assert_same(got, ref)
     eng.close()
+
+
+@pytest.mark.parametrize("ncols,n,pinned,flags", [(2, 260, True, 0), (3, 131, False, 8), (2, 5, True, 0)])
+def test_pipelined_host_delivery(engine_factory, oracle, hsw, ncols, n, pinned, flags):
+    """hsw_witness_blocks_host with an aligned cursor: chunks of <=128 blocks are
+    expanded into two staging slots while the previous chunk drains over PCIe."""
+    eng = engine_factory(8, ncols)
+    blocks, pre = _rand_inputs(n, 31337 + n)
+    cursor0 = 6 * ncols
+    got = eng.witness_blocks_host(blocks, pre, cursor0=cursor0, flags=flags, pinned=pinned)
+    ref = oracle.Oracle(8, ncols, check=False).witness_blocks(blocks, pre, cursor0=cursor0)
+    assert np.array_equal(got["gate"], ref["gate"])
+    assert np.array_equal(got["dense"], ref["dense"]) and np.array_equal(got["spread"], ref["spread"])
+    assert np.array_equal(got["next_states"], ref["next_states"])
