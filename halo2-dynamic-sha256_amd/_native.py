@@ -25,6 +25,9 @@ HSW_REPR_MONTGOMERY = 1
 HSW_SKIP_GATE = 2
 HSW_SKIP_CHIP = 4
 HSW_HOST_REGISTER = 8
+HSW_MODE_DEFAULT = 0
+HSW_MODE_HALO2_INTERNALS = 1
+HSW_MAX_BREAKS = 8
 HSW_CELL_BYTES = 32
 
 
@@ -35,10 +38,25 @@ class Shape(C.Structure):
         "cells_per_sched_step", "cells_per_round", "off_words", "off_msg_spread", "off_sched",
         "off_state_spread", "off_rounds", "off_feed", "gate_cells_per_block",
         "spread_calls_per_block", "limb_calls_per_block", "chip_cells_per_block")] + [
-        ("algorithmic_bytes_per_block", C.c_uint64)]
+        ("algorithmic_bytes_per_block", C.c_uint64), ("mode", C.c_uint32),
+        ("lookup_cells_per_block", C.c_uint32), ("gate_calls_per_block", C.c_uint32),
+        ("reserved_", C.c_uint32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PackPlan(C.Structure):
+    _fields_ = [("n_breaks", C.c_uint32), ("columns_touched", C.c_uint32),
+                ("break_cell", C.c_uint64 * 8), ("break_gap", C.c_uint64 * 8),
+                ("span_cells", C.c_uint64), ("end_row", C.c_uint64)]
+
+
+class WitnessArgs(C.Structure):
+    _fields_ = [("d_blocks", C.c_void_p), ("d_pre_states", C.c_void_p), ("n_blocks", C.c_size_t),
+                ("spread_cursor0", C.c_uint64), ("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p),
+                ("d_chip_spread", C.c_void_p), ("chip_col_stride", C.c_size_t), ("d_next_states", C.c_void_p),
+                ("d_lookup", C.c_void_p), ("flags", C.c_uint32), ("pack", C.POINTER(PackPlan))]
 
 
 class DigestInfo(C.Structure):
@@ -67,6 +85,8 @@ SYMBOLS = (
     "hsw_engine_stream", "hsw_digest_prepare", "hsw_gadget_create", "hsw_gadget_destroy",
     "hsw_gadget_digest", "hsw_gadget_digest_batch", "hsw_gadget_streams", "hsw_gadget_input_bytes",
     "hsw_gadget_set_repr", "hsw_download", "hsw_host_alloc", "hsw_host_free",
+    "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
+    "hsw_witness_blocks_ex",
 )
 
 
@@ -146,6 +166,16 @@ def lib():
         L.hsw_gadget_streams.argtypes = [vp, C.POINTER(GadgetView)]
         L.hsw_gadget_input_bytes.restype = C.c_int
         L.hsw_gadget_input_bytes.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hsw_shape_query_ex.restype = C.c_int
+        L.hsw_shape_query_ex.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Shape)]
+        L.hsw_engine_create_ex.restype = C.c_int
+        L.hsw_engine_create_ex.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.hsw_pack_plan_query.restype = C.c_int
+        L.hsw_pack_plan_query.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_uint64, C.c_uint64, C.POINTER(PackPlan)]
+        L.hsw_gate_tape.restype = C.c_int
+        L.hsw_gate_tape.argtypes = [C.POINTER(Shape), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hsw_witness_blocks_ex.restype = C.c_int
+        L.hsw_witness_blocks_ex.argtypes = [vp, C.POINTER(WitnessArgs)]
         L.hsw_host_alloc.restype = C.c_int
         L.hsw_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.hsw_host_free.restype = None
@@ -180,9 +210,31 @@ def digest_prepare(message: bytes, max_variable_byte_size: int, precomputed_inpu
     return blocks[:max_variable_byte_size], init, {k: int(getattr(info, k)) for k, _ in DigestInfo._fields_}
 
 
-def shape_query(num_bits_lookup=8, num_advice_columns=2):
+def shape_query(num_bits_lookup=8, num_advice_columns=2, mode=HSW_MODE_DEFAULT):
     s = Shape()
-    rc = lib().hsw_shape_query(num_bits_lookup, num_advice_columns, C.byref(s))
+    rc = lib().hsw_shape_query_ex(num_bits_lookup, num_advice_columns, mode, C.byref(s))
     if rc != HSW_OK:
         raise HswError(rc)
     return s
+
+
+def gate_tape(shape):
+    """assign_region call lengths of one block (numpy uint8), hsw_gate_tape."""
+    import numpy as np
+    n = C.c_size_t()
+    rc = lib().hsw_gate_tape(C.byref(shape), None, 0, C.byref(n))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    lens = np.zeros(n.value, dtype=np.uint8)
+    rc = lib().hsw_gate_tape(C.byref(shape), lens.ctypes.data, lens.size, None)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return lens
+
+
+def pack_plan(shape, n_blocks, start_row, max_rows):
+    p = PackPlan()
+    rc = lib().hsw_pack_plan_query(C.byref(shape), n_blocks, start_row, max_rows, C.byref(p))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return p

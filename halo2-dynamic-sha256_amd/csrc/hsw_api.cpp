@@ -14,6 +14,7 @@
 #include "../../include/hsw.h"
 #include "hsw_kernels.h"
 #include "hsw_layout.h"
+#include "hsw_tape.hpp"
 
 struct hsw_engine {
     int device = 0;
@@ -22,6 +23,7 @@ struct hsw_engine {
     int limbs = 2;
     int parts = 0;             // waves per block; 0 = choose from the batch size
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
+    uint32_t mode = HSW_MODE_DEFAULT;
     bool timing = false;
     bool timed = false;        // ev0/ev1 bracket a launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -38,9 +40,12 @@ struct hsw_engine {
 
 namespace {
 
-template <int L>
+template <int L, bool RC>
 void fill_shape(hsw_shape *s) {
-    using LY = hsw::Lay<L>;
+    using LY = hsw::Lay<L, RC>;
+    s->lookup_cells_per_block = LY::LOOKUP_CELLS;
+    s->mode = RC ? HSW_MODE_HALO2_INTERNALS : HSW_MODE_DEFAULT;
+    s->gate_calls_per_block = (uint32_t)hsw::TapeBuilder(L, RC).block().size();
     s->limbs_per_spread = LY::LIMBS;
     s->cells_per_spread = LY::S;
     s->cells_per_state_spread = LY::S2S;
@@ -132,7 +137,13 @@ const char *hsw_strerror(int status) {
 const char *hsw_last_error(const hsw_engine *e) { return e ? e->err.c_str() : ""; }
 
 int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out) {
+    return hsw_shape_query_ex(num_bits_lookup, num_advice_columns, HSW_MODE_DEFAULT, out);
+}
+
+int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode, hsw_shape *out) {
     if (!out) return HSW_ERR_INVALID_ARG;
+    if (mode != HSW_MODE_DEFAULT && mode != HSW_MODE_HALO2_INTERNALS) return HSW_ERR_INVALID_ARG;
+    const bool rc = mode == HSW_MODE_HALO2_INTERNALS;
     // spread.rs:37 debug_assert_eq!(16 % num_bits_lookup, 0)
     if (num_bits_lookup == 0 || num_bits_lookup > 16 || 16 % num_bits_lookup != 0) return HSW_ERR_SHAPE;
     if (num_advice_columns == 0) return HSW_ERR_SHAPE;
@@ -140,11 +151,11 @@ int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_s
     out->num_bits_lookup = num_bits_lookup;
     out->num_advice_columns = num_advice_columns;
     switch (16 / num_bits_lookup) {
-        case 1: fill_shape<1>(out); break;
-        case 2: fill_shape<2>(out); break;
-        case 4: fill_shape<4>(out); break;
-        case 8: fill_shape<8>(out); break;
-        case 16: fill_shape<16>(out); break;
+        case 1: rc ? fill_shape<1, true>(out) : fill_shape<1, false>(out); break;
+        case 2: rc ? fill_shape<2, true>(out) : fill_shape<2, false>(out); break;
+        case 4: rc ? fill_shape<4, true>(out) : fill_shape<4, false>(out); break;
+        case 8: rc ? fill_shape<8, true>(out) : fill_shape<8, false>(out); break;
+        case 16: rc ? fill_shape<16, true>(out) : fill_shape<16, false>(out); break;
         default: return HSW_ERR_SHAPE;
     }
     return HSW_OK;
@@ -158,12 +169,18 @@ uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) 
 
 int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
                       uint32_t num_advice_columns, hsw_engine **out) {
+    return hsw_engine_create_ex(device, hip_stream, num_bits_lookup, num_advice_columns, HSW_MODE_DEFAULT, out);
+}
+
+int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
+                         uint32_t num_advice_columns, uint32_t mode, hsw_engine **out) {
     if (!out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape shape;
-    int rc = hsw_shape_query(num_bits_lookup, num_advice_columns, &shape);
+    int rc = hsw_shape_query_ex(num_bits_lookup, num_advice_columns, mode, &shape);
     if (rc != HSW_OK) return rc;
     if (shape.limbs_per_spread > 4) return HSW_ERR_UNSUPPORTED;   // kernels built for 16/8/4-bit tables
+    if (mode == HSW_MODE_HALO2_INTERNALS && shape.limbs_per_spread != 2) return HSW_ERR_UNSUPPORTED;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HSW_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return HSW_ERR_NO_DEVICE;
@@ -172,6 +189,7 @@ int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
     e->device = device;
     e->stream = static_cast<hipStream_t>(hip_stream);
     e->shape = shape;
+    e->mode = mode;
     e->limbs = (int)shape.limbs_per_spread;
     DeviceScope ds(device);
     if (!ds.ok) { delete e; return HSW_ERR_NO_DEVICE; }
@@ -267,7 +285,23 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
                        size_t n_blocks, uint64_t spread_cursor0, void *d_gate, void *d_chip_dense,
                        void *d_chip_spread, size_t chip_col_stride, uint32_t *d_next_states,
                        uint32_t flags) {
-    if (!e) return HSW_ERR_INVALID_ARG;
+    hsw_witness_args a{};
+    a.d_blocks = d_blocks; a.d_pre_states = d_pre_states; a.n_blocks = n_blocks;
+    a.spread_cursor0 = spread_cursor0; a.d_gate = d_gate; a.d_chip_dense = d_chip_dense;
+    a.d_chip_spread = d_chip_spread; a.chip_col_stride = chip_col_stride;
+    a.d_next_states = d_next_states; a.flags = flags;
+    return hsw_witness_blocks_ex(e, &a);
+}
+
+int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
+    if (!e || !args) return HSW_ERR_INVALID_ARG;
+    const uint8_t *d_blocks = args->d_blocks;
+    const uint32_t *d_pre_states = args->d_pre_states;
+    const size_t n_blocks = args->n_blocks, chip_col_stride = args->chip_col_stride;
+    const uint64_t spread_cursor0 = args->spread_cursor0;
+    void *d_gate = args->d_gate, *d_chip_dense = args->d_chip_dense, *d_chip_spread = args->d_chip_spread;
+    uint32_t *d_next_states = args->d_next_states;
+    const uint32_t flags = args->flags;
     if (n_blocks == 0) return HSW_OK;
     if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP))
         return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
@@ -284,12 +318,19 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         if (chip_col_stride < hsw_chip_rows(&e->shape, spread_cursor0, n_blocks))
             return set_err(e, HSW_ERR_INVALID_ARG, "chip_col_stride smaller than hsw_chip_rows()");
     }
+    if (args->d_lookup && e->mode != HSW_MODE_HALO2_INTERNALS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "d_lookup needs an engine created with HSW_MODE_HALO2_INTERNALS");
+    if (args->d_lookup && ((uintptr_t)args->d_lookup & 15u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "lookup buffer not 16-byte aligned");
+    if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
 
     // One launch covers up to 2^20 blocks (2.5 TB of cells would be far past
     // HBM anyway); longer batches are issued as consecutive launches.
     const size_t CHUNK = (size_t)1 << 20;
+    const size_t G = e->shape.gate_cells_per_block;
     hipError_t he;
     if (e->timing) {
         he = hipEventRecord(e->ev0, e->stream);
@@ -300,22 +341,31 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         hsw::ExpandParams p{};
         p.blocks = d_blocks + 64 * done;
         p.pre_states = d_pre_states + 8 * done;
-        p.gate = want_gate ? static_cast<uint8_t *>(d_gate) +
-                                 (size_t)HSW_CELL_BYTES * e->shape.gate_cells_per_block * done
-                           : nullptr;
-        // the chip pass addresses rows from the *call's* cursor0, so chunks only
-        // move the cursor forward
+        p.gate = want_gate ? static_cast<uint8_t *>(d_gate) + (size_t)HSW_CELL_BYTES * G * done : nullptr;
         p.chip_dense = d_chip_dense;
         p.chip_spread = d_chip_spread;
         p.next_states = d_next_states ? d_next_states + 8 * done : nullptr;
+        p.lookup = args->d_lookup ? static_cast<uint8_t *>(args->d_lookup) +
+                                        (size_t)HSW_CELL_BYTES * e->shape.lookup_cells_per_block * done
+                                  : nullptr;
         p.n_blocks = n;
         p.chip_col_stride = chip_col_stride;
         p.cursor0 = spread_cursor0;
         p.ncols = e->shape.num_advice_columns;
         p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP) |
-                  ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY ? hsw::HSW_K_MONTGOMERY : 0u);
+                  ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY ? hsw::HSW_K_MONTGOMERY : 0u) |
+                  (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u);
         const int tile = choose_tile(e, (flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY);
         p.parts = (uint32_t)choose_parts(e, n_blocks, tile);
+        if (args->pack) {
+            // breaks are given in call-relative stream indices; this launch starts at cell done*G
+            for (uint32_t k = 0; k < args->pack->n_breaks; k++) {
+                const uint64_t bc = args->pack->break_cell[k], first = (uint64_t)done * G;
+                p.break_cell[p.n_breaks] = bc > first ? bc - first : 0;
+                p.break_gap[p.n_breaks] = args->pack->break_gap[k];
+                p.n_breaks++;
+            }
+        }
         if (done != 0) {
             // later chunks: keep buffer row 0 fixed by pre-offsetting the column
             // base instead of the cursor origin
@@ -336,6 +386,52 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
         e->timed = true;
     }
+    return HSW_OK;
+}
+
+int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls) {
+    if (!shape || shape->limbs_per_spread == 0) return HSW_ERR_INVALID_ARG;
+    const std::vector<uint8_t> lens =
+        hsw::TapeBuilder((int)shape->limbs_per_spread, shape->mode == HSW_MODE_HALO2_INTERNALS).block();
+    if (n_calls) *n_calls = lens.size();
+    if (lens_out) {
+        if (cap < lens.size()) return HSW_ERR_INVALID_ARG;
+        std::memcpy(lens_out, lens.data(), lens.size());
+    }
+    return HSW_OK;
+}
+
+int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_row, uint64_t max_rows,
+                        hsw_pack_plan *out) {
+    if (!shape || !out || shape->limbs_per_spread == 0) return HSW_ERR_INVALID_ARG;
+    if (max_rows < 8 || start_row >= max_rows) return HSW_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const std::vector<uint8_t> lens =
+        hsw::TapeBuilder((int)shape->limbs_per_spread, shape->mode == HSW_MODE_HALO2_INTERNALS).block();
+    const uint64_t G = shape->gate_cells_per_block;
+    uint64_t row = start_row, cell = 0, gaps = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+        if (row + G + 4 < max_rows) {          // no call of this block can reach the end of the column
+            row += G;
+            cell += G;
+            continue;
+        }
+        for (uint8_t len : lens) {
+            if (row + len >= max_rows) {       // halo2-lib v0.2.x assign_region: move to the next column (A3)
+                if (out->n_breaks == HSW_MAX_BREAKS) return HSW_ERR_TOO_LARGE;
+                out->break_cell[out->n_breaks] = cell;
+                out->break_gap[out->n_breaks] = max_rows - row;
+                out->n_breaks++;
+                gaps += max_rows - row;
+                row = 0;
+            }
+            row += len;
+            cell += len;
+        }
+    }
+    out->columns_touched = out->n_breaks + 1;
+    out->span_cells = cell + gaps;
+    out->end_row = row;
     return HSW_OK;
 }
 

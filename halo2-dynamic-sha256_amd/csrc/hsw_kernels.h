@@ -13,7 +13,9 @@ enum : uint32_t {
     HSW_K_MONTGOMERY = 1u,   // mirrors HSW_REPR_MONTGOMERY
     HSW_K_SKIP_GATE = 2u,    // mirrors HSW_SKIP_GATE
     HSW_K_SKIP_CHIP = 4u,    // mirrors HSW_SKIP_CHIP
+    HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
 };
+enum { HSW_K_MAX_BREAKS = 8 };
 
 struct ExpandParams {
     const uint8_t *blocks;        // n_blocks * 64 bytes
@@ -28,6 +30,11 @@ struct ExpandParams {
     uint32_t ncols;               // num_advice_columns
     uint32_t flags;               // HSW_K_*
     uint32_t parts;               // waves per block: 1, 2, 4, 8 or 16
+    void *lookup;                 // n_blocks * LOOKUP_CELLS cells (internals mode), may be null
+    // FlexGate column packing: gate cell i is written at i + sum of break_gap[k] over break_cell[k] <= i
+    uint32_t n_breaks;
+    uint64_t break_cell[HSW_K_MAX_BREAKS];
+    uint64_t break_gap[HSW_K_MAX_BREAKS];
 };
 
 // limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count

@@ -182,10 +182,11 @@ DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
 // rest is wave-uniform.  WHERE a cell goes inside the tile is not state at all:
 // it is the compile-time cursor type below, so every emitted cell is one
 // ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
-template <int T, int R, bool MONT_>
+template <int T, int R, bool MONT_, bool RC_>
 struct Em {
     static constexpr int TILE = T, ROWS = R;
     static constexpr bool MONT = MONT_;
+    static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
     u64 *row;          // this lane's tile row (LDS)
     const u64 *tile;   // tile base (LDS)
     u16 *d16;          // staged dense inputs of spread() calls (LDS)
@@ -199,6 +200,14 @@ struct Em {
     u32 calls;         // spread calls staged by this phase-part (nrows * calls_per_unit)
     bool active;       // lane < nrows
     bool write_gate;   // HSW_SKIP_GATE not set
+    // FlexGate column packing: cells at block-local index >= brk1 / brk2 are shifted
+    // by gap1 / gap2 more cells (the unused tail rows of a column); 0xffffffff = none
+    u32 brk1, gap1, brk2, gap2;
+    // lookup-advice column staging (RC only)
+    u16 *lk16;         // LDS
+    u32 lk;            // this lane's next slot (phase-local)
+    u32 lk_first;      // block-relative index of the phase-part's first lookup cell
+    u32 lks;           // lookup cells staged by this phase-part
 };
 
 // Compile-time emission cursor: POS = cells already in the current tile, FL =
@@ -232,7 +241,8 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
                     const u64 mword = (T > 64 && p >= 64u) ? neg1 : neg0;
                     if (((mword >> (p & 63u)) & 1ull) && v != 0ull) m = fe_neg_nonzero(m);
                 }
-                uint4 *dst = em.out + (size_t)(em.cell_base + seg + r * em.unit_cells + p) * 2u;
+                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                uint4 *dst = em.out + ((size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)) * 2u;
                 dst[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
                 dst[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
             }
@@ -261,7 +271,8 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
                         o.w = h ? HSW_P7 : HSW_P3;
                     }
                 }
-                em.out[(size_t)(em.cell_base + seg + r * em.unit_cells + p) * 2u + h] = o;
+                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                em.out[((size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)) * 2u + h] = o;
             }
         }
     }
@@ -303,7 +314,7 @@ DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
 // Returns false if this wave has nothing to do in the phase (wave-uniform).
 template <class EM>
 DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
-                     u32 call_base, u32 calls_per_unit) {
+                     u32 call_base, u32 calls_per_unit, u32 lk_base = 0, u32 lk_per_unit = 0) {
     const u32 lane = threadIdx.x;
     u32 nrows, unit_lo;
     if (n_units % parts == 0) {
@@ -322,6 +333,9 @@ DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u
     em.call = r * calls_per_unit;
     em.call_first = call_base + unit_lo * calls_per_unit;
     em.calls = nrows * calls_per_unit;
+    em.lk = r * lk_per_unit;
+    em.lk_first = lk_base + unit_lo * lk_per_unit;
+    em.lks = nrows * lk_per_unit;
     return nrows != 0;
 }
 
@@ -378,10 +392,61 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
     __syncthreads();
 }
 
+// Lookup-advice column (RC only): the values queued by enable_lookup, in queue
+// order, as one contiguous run per phase-part (RangeConfig::finalize, lib.rs:469).
+template <class EM>
+DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_base) {
+    if (em.lks == 0 || p.lookup == nullptr) return;
+    __syncthreads();
+    const u32 lane = threadIdx.x;
+    uint4 *out = reinterpret_cast<uint4 *>(p.lookup) + (lookup_block_base + em.lk_first) * 2u;
+    if constexpr (EM::MONT) {
+        for (u32 k = lane; k < em.lks; k += 64) {
+            const Fe8 m = mont_from_u64<false>(em.lk16[k], 0);
+            out[2 * k] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+            out[2 * k + 1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+        }
+    } else {
+        for (u32 i = lane; i < 2u * em.lks; i += 64) {
+            uint4 o;
+            o.x = (i & 1u) ? 0u : (u32)em.lk16[i >> 1];
+            o.y = 0; o.z = 0; o.w = 0;
+            out[i] = o;
+        }
+    }
+    __syncthreads();
+}
+
 template <int L, class EM, class C>
-DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb) {
+DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
     if constexpr (C::pos != 0) flush_tile(em, C::pos, C::fl * EM::TILE, C::n0, C::n1);
     flush_chip<L>(em, p, block_first_limb);
+    if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
+}
+
+// enable_lookup: queue a (<= 16-bit) value for the lookup-advice column
+template <class EM>
+DEV void lookup16(EM &em, u32 v) {
+    if constexpr (EM::RC) {
+        if (em.active) em.lk16[em.lk] = (u16)v;
+        em.lk++;
+    }
+}
+// range_check(a, 32) at lookup_bits = 16: halo2-base lays out [limb0, limb1, 2^16, a]
+// (inner_product_left of the two limbs with [1, 2^16]) and looks both limbs up (A3).
+template <class EM, class C>
+DEV auto range_check32(C c, EM &em, u32 a) {
+    const u32 l0 = a & 0xffffu, l1 = a >> 16;
+    lookup16(em, l0);
+    lookup16(em, l1);
+    if constexpr (EM::RC) {
+        auto c1 = emit(c, em, l0);
+        auto c2 = emit(c1, em, l1);
+        auto c3 = emit(c2, em, 1u << 16);
+        return emit(c3, em, a);
+    } else {
+        return c;
+    }
 }
 
 // ---------------------------------------------------- halo2-base gate cells
@@ -470,7 +535,8 @@ DEV auto mod_u32(C c, EM &em, u64 x, u32 &lo_out) {
     lo_out = lo;
     auto c1 = g_lw(c, em, lo);                               // :280
     auto c2 = g_lw(c1, em, hi);                              // :281
-    return g_mul_add(c2, em, hi, (u64)1 << 32, lo, x);       // :283-288
+    auto c3 = range_check32(c2, em, lo);                     // :282
+    return g_mul_add(c3, em, hi, (u64)1 << 32, lo, x);       // :283-288
 }
 
 // { spread(even); spread(odd); 2*odd_spread + even_spread } (compression.rs:344-354 etc.)
@@ -545,8 +611,10 @@ DEV auto sigma_generic(C c0, EM &em, u32 x, u32 &out) {
     auto c12 = g_mul_add(c11, em, SG::C3, pd, r3, r);
     // :811-836
     const u32 r_lo = (u32)r, r_hi = (u32)(r >> 32);
-    auto c13 = g_lw(c12, em, r_lo);
-    auto c14 = g_lw(c13, em, r_hi);
+    auto c13 = g_lw(c12, em, r_lo);                          // :820
+    auto c14a = g_lw(c13, em, r_hi);                         // :821
+    auto c14b = range_check32(c14a, em, r_lo);               // :822
+    auto c14 = range_check32(c14b, em, r_hi);                // :823
     auto c15 = g_mul_add(c14, em, r_hi, 1ull << 32, r_lo, r);
     // :843-846
     const u32 lo_even = even_bits(r_lo), lo_odd = even_bits(r_lo >> 1);
@@ -555,6 +623,8 @@ DEV auto sigma_generic(C c0, EM &em, u32 x, u32 &out) {
     auto c17 = g_lw(c16, em, lo_odd);
     auto c18 = g_lw(c17, em, hi_even);
     auto c19 = g_lw(c18, em, hi_odd);
+    lookup16(em, lo_even); lookup16(em, lo_odd);             // range_check 16, spread.rs:160-161
+    lookup16(em, hi_even); lookup16(em, hi_odd);
     auto c20 = recheck_even_odd<L>(c19, em, lo_even, lo_odd);     // :852-862
     auto c21 = recheck_even_odd<L>(c20, em, hi_even, hi_odd);     // :863-873
     out = (hi_even << 16) | lo_even;
@@ -605,6 +675,8 @@ DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     auto c26 = g_lw(c25, em, q_lo_odd);
     auto c27 = g_lw(c26, em, q_hi_even);
     auto c28 = g_lw(c27, em, q_hi_odd);
+    lookup16(em, p_lo_even); lookup16(em, p_lo_odd); lookup16(em, p_hi_even); lookup16(em, p_hi_odd);
+    lookup16(em, q_lo_even); lookup16(em, q_lo_odd); lookup16(em, q_hi_even); lookup16(em, q_hi_odd);
     auto c29 = recheck_even_odd<L>(c28, em, p_lo_even, p_lo_odd);     // :344-354
     auto c30 = recheck_even_odd<L>(c29, em, p_hi_even, p_hi_odd);     // :355-365
     auto c31 = recheck_even_odd<L>(c30, em, q_lo_even, q_lo_odd);     // :366-376
@@ -634,6 +706,7 @@ DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     auto c6 = g_lw(c5, em, m_lo_odd);
     auto c7 = g_lw(c6, em, m_hi_even);                       // :488-489
     auto c8 = g_lw(c7, em, m_hi_odd);
+    lookup16(em, m_lo_even); lookup16(em, m_lo_odd); lookup16(em, m_hi_even); lookup16(em, m_hi_odd);
     auto c9 = recheck_even_odd<L>(c8, em, m_lo_even, m_lo_odd);      // :490-500
     auto c10 = recheck_even_odd<L>(c9, em, m_hi_even, m_hi_odd);     // :501-511
     out = (m_hi_odd << 16) | m_lo_odd;
@@ -643,9 +716,9 @@ DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
 // --------------------------------------------------------------- the kernel
 // T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
 // units one wave expands per phase; a block needs parts >= 64/R waves.
-template <int L, int T, int R, bool MONT>
+template <int L, int T, int R, bool MONT, bool RC>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
-    using LY = Lay<L>;
+    using LY = Lay<L, RC>;
     static_assert(R * (T + 1) * 8 >= 800, "tile must be able to hold the chain seeds");
     // The chain seeds live in LDS only until every lane has pulled its own into
     // registers; the tile then reuses the same bytes (keeps the workgroup at
@@ -656,6 +729,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     u32 *sA = sW + 64;         // [68] sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
     u32 *sE = sA + 68;         // [68] sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
     __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
+    __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
 
     const u32 lane = threadIdx.x;
     const u32 parts = p.parts;                   // waves per block (power of two <= 16)
@@ -716,12 +790,28 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
     __syncthreads();           // seeds are in registers: the tile may now overwrite them
 
-    using EM = Em<T, R, MONT>;
+    using EM = Em<T, R, MONT, RC>;
     EM em;
+    em.lk16 = s_lk16;
     em.tile = s_tile;
     em.row = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 1);   // lanes >= R never flush: scratch row
     em.d16 = s_d16;
-    em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)blk * (size_t)LY::GATE_CELLS * 2u;
+    {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
+        const u64 first = (u64)blk * (u64)LY::GATE_CELLS;
+        u64 gap0 = 0;
+        em.brk1 = em.brk2 = 0xffffffffu;
+        em.gap1 = em.gap2 = 0;
+        for (u32 k = 0; k < p.n_breaks; k++) {
+            const u64 bc = p.break_cell[k];
+            if (bc <= first) gap0 += p.break_gap[k];
+            else if (bc < first + (u64)LY::GATE_CELLS) {
+                if (em.brk1 == 0xffffffffu) { em.brk1 = (u32)(bc - first); em.gap1 = (u32)p.break_gap[k]; }
+                else { em.brk2 = (u32)(bc - first); em.gap2 = (u32)p.break_gap[k]; }
+            }
+        }
+        em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)(first + gap0) * 2u;
+    }
+    const size_t lk_blk = (size_t)blk * (size_t)LY::LOOKUP_CELLS;
     em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
     const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
 
@@ -734,17 +824,18 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         auto c2 = g_mul_add(c1, em, b1, 1u << 8, s0, s1);
         auto c3 = g_mul_add(c2, em, b2, 1u << 16, s1, s2);
         auto c4 = g_mul_add(c3, em, b3, 1u << 24, s2, word);
-        phase_end<L>(c4, em, p, blk_limb0);
+        phase_end<L>(c4, em, p, blk_limb0, lk_blk);
     }
 
     // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
     if (phase_begin(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
         auto c1 = state_to_spread<L>(CurStart{}, em, seed_word);
-        phase_end<L>(c1, em, p, blk_limb0);
+        phase_end<L>(c1, em, p, blk_limb0, lk_blk);
     }
 
     // ---- schedule: compression.rs:57-96, 48 units --------------------------
-    if (phase_begin(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED)) {
+    if (phase_begin(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED,
+                    LY::LK_OFF_SCHED, LY::LK_SCHED)) {
         const u32 w2 = seed_w2, w15 = seed_w15, w7 = seed_w7, w16 = seed_w16;   // W[idx-2], [idx-15], [idx-7], [idx-16]
         u32 term1, term3, new_w;
         u64 sum;
@@ -755,17 +846,18 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         auto c5 = g_add(c4, em, sum, w16, sum);                                // :75-79
         auto c6 = mod_u32(c5, em, sum, new_w);                                 // :80
         auto c7 = state_to_spread<L>(c6, em, new_w);                           // :90
-        phase_end<L>(c7, em, p, blk_limb0);
+        phase_end<L>(c7, em, p, blk_limb0, lk_blk);
     }
 
     // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
     if (phase_begin(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
         auto c1 = state_to_spread<L>(CurStart{}, em, seed_state);
-        phase_end<L>(c1, em, p, blk_limb0);
+        phase_end<L>(c1, em, p, blk_limb0, lk_blk);
     }
 
     // ---- 64 rounds: compression.rs:125-196 ---------------------------------
-    if (phase_begin(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND)) {
+    if (phase_begin(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND,
+                    LY::LK_OFF_ROUNDS, LY::LK_ROUND)) {
         const u32 a = seed_a, b = seed_b, c = seed_c, d = seed_d;
         const u32 e = seed_e, f = seed_f, g = seed_g, h = seed_h;
         u32 sig1, chv, t1, sig0, mjv, t2, e_new, a_new;
@@ -787,16 +879,16 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         auto c15 = g_add(c14, em, t1, t2, s);                                  // :192
         auto c16 = mod_u32(c15, em, s, a_new);                                 // :193
         auto c17 = state_to_spread<L>(c16, em, a_new);                         // :195
-        phase_end<L>(c17, em, p, blk_limb0);
+        phase_end<L>(c17, em, p, blk_limb0, lk_blk);
     }
 
     // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
-    if (phase_begin(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0)) {
+    if (phase_begin(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
         u64 s;
         u32 lo;
         auto c1 = g_add(CurStart{}, em, seed_fx, seed_fy, s);
         auto c2 = mod_u32(c1, em, s, lo);
-        phase_end<L>(c2, em, p, blk_limb0);
+        phase_end<L>(c2, em, p, blk_limb0, lk_blk);
     }
 }
 
@@ -872,24 +964,29 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ launch
-template <int L, int T, int R>
+template <int L, int T, int R, bool RC>
 static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
     if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
     const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
     if (p.flags & HSW_K_MONTGOMERY)
-        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, true, RC>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, false>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, false, RC>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
+    if (p.flags & HSW_K_INTERNALS) {
+        // halo2-base internals (A3) are built for the reference's 8-bit table only, 32-cell tiles
+        if constexpr (L == 2) return launch_expand_LTR<L, 32, 64, true>(p, stream);
+        else return hipErrorInvalidValue;
+    }
     switch (tile) {
-        case 32: return launch_expand_LTR<L, 32, 64>(p, stream);
-        case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32>(p, stream); else return hipErrorInvalidValue;
-        case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16>(p, stream); else return hipErrorInvalidValue;
+        case 32: return launch_expand_LTR<L, 32, 64, false>(p, stream);
+        case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32, false>(p, stream); else return hipErrorInvalidValue;
+        case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16, false>(p, stream); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -17,20 +17,27 @@
 //   round             compression.rs:125-196  2 sigma + ch + maj + 7 add + 4 mod
 //                                             + 2 s2s                             = 280 + 24 S
 // with L = 16 / num_bits_lookup limbs per spread and S = 10 L.
+//
+// RC = true adds halo2-base's own cells of every range_check(a, 32) at the call
+// position: [limb0, limb1, 2^16, a] (DESIGN.md assumption A3; range_check(a, 16)
+// adds none at lookup_bits = 16): +4 per mod_u32, +8 per sigma_generic.
+// Independently of RC, LK_* count the cells queued for the lookup-advice column
+// (2 limbs per range_check 32, 1 value per range_check 16), in call order.
 #ifndef HSW_LAYOUT_H
 #define HSW_LAYOUT_H
 
 namespace hsw {
 
-template <int L>
+template <int L, bool RC = false>
 struct Lay {
     static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "16 % num_bits_lookup == 0");
     static constexpr int LIMBS = L;
     static constexpr int LIMB_BITS = 16 / L;
     static constexpr int S = 10 * L;            // cells per spread()
     static constexpr int S2S = 6 + 2 * S;       // state_to_spread_u32
-    static constexpr int MOD = 6;               // mod_u32
-    static constexpr int SIGMA = 58 + 4 * S;
+    static constexpr int RC32 = RC ? 4 : 0;     // halo2-base cells of one range_check(a, 32)
+    static constexpr int MOD = 6 + RC32;        // mod_u32
+    static constexpr int SIGMA = 58 + 4 * S + 2 * RC32;
     static constexpr int CH = 68 + 8 * S;
     static constexpr int MAJ = 32 + 4 * S;
     static constexpr int SCHED = 2 * SIGMA + 12 + MOD + S2S;
@@ -59,11 +66,25 @@ struct Lay {
     static constexpr int SPREAD_CALLS = CALL_ROUNDS + 64 * CALLS_ROUND;             // 2060
     static constexpr int LIMB_CALLS = SPREAD_CALLS * L;
     static constexpr int CHIP_CELLS = 2 * LIMB_CALLS;
+
+    // lookup-advice column entries, in enable_lookup order
+    static constexpr int LK_MOD = 2;                                  // range_check(lo, 32)
+    static constexpr int LK_SIGMA = 2 * 2 + 4;                        // 2 x range_check 32 + 4 x range_check 16
+    static constexpr int LK_CH = 8, LK_MAJ = 4;                       // even/odd range_check 16
+    static constexpr int LK_SCHED = 2 * LK_SIGMA + LK_MOD;            // 18
+    static constexpr int LK_ROUND = 2 * LK_SIGMA + LK_CH + LK_MAJ + 4 * LK_MOD;   // 36
+    static constexpr int LK_FEED = LK_MOD;
+    static constexpr int LK_OFF_SCHED = 0;
+    static constexpr int LK_OFF_ROUNDS = LK_OFF_SCHED + 48 * LK_SCHED;            // 864
+    static constexpr int LK_OFF_FEED = LK_OFF_ROUNDS + 64 * LK_ROUND;             // 3168
+    static constexpr int LOOKUP_CELLS = LK_OFF_FEED + 8 * LK_FEED;                // 3184
 };
 
 static_assert(Lay<2>::ROUND == 760 && Lay<2>::SCHED == 340 && Lay<2>::GATE_CELLS == 66308,
               "SURVEY 8a per-block tallies at num_bits_lookup = 8");
 static_assert(Lay<2>::SPREAD_CALLS == 2060 && Lay<2>::CHIP_CELLS == 8240, "SURVEY 8a");
+static_assert(Lay<2, true>::GATE_CELLS == 66308 + 760 * 4, "760 range_check(32) per block (SURVEY 8a)");
+static_assert(Lay<2>::LOOKUP_CELLS == 3184, "SURVEY 8c: ~3,184 lookup-column copies per block");
 
 }  // namespace hsw
 #endif

@@ -32,7 +32,8 @@ class WitnessEngine:
     num_limb_sum cursor (spread.rs:26) is an explicit argument of every call.
     """
 
-    def __init__(self, device=0, num_bits_lookup=8, num_advice_columns=2, stream=None):
+    def __init__(self, device=0, num_bits_lookup=8, num_advice_columns=2, stream=None,
+                 mode=N.HSW_MODE_DEFAULT):
         import torch  # plumbing only
         self.torch = torch
         self.lib = N.lib()
@@ -43,8 +44,8 @@ class WitnessEngine:
             stream = torch.cuda.current_stream(self.device)
         self.stream = stream
         h = C.c_void_p()
-        rc = self.lib.hsw_engine_create(device, C.c_void_p(stream.cuda_stream), num_bits_lookup,
-                                        num_advice_columns, C.byref(h))
+        rc = self.lib.hsw_engine_create_ex(device, C.c_void_p(stream.cuda_stream), num_bits_lookup,
+                                           num_advice_columns, mode, C.byref(h))
         if rc != N.HSW_OK:
             raise N.HswError(rc)
         self.h = h
@@ -54,6 +55,8 @@ class WitnessEngine:
         self.G = int(s.gate_cells_per_block)
         self.ncols = int(s.num_advice_columns)
         self.limb_calls = int(s.limb_calls_per_block)
+        self.lookup_cells = int(s.lookup_cells_per_block)
+        self.mode = mode
 
     def close(self):
         if getattr(self, "h", None):
@@ -105,6 +108,35 @@ class WitnessEngine:
             nxt.data_ptr() if nxt is not None else None, flags)
         self._ok(rc)
         return out
+
+    def witness_blocks_ex(self, blocks, pre_states, cursor0=0, flags=0, want_lookup=False,
+                          start_row=0, max_rows=None):
+        """hsw_witness_blocks_ex: optional lookup-column stream (internals mode) and
+        FlexGate column packing.  With max_rows the gate output is a flat buffer of
+        plan.span_cells cells whose cell 0 is (first column, start_row)."""
+        t = self.torch
+        n = blocks.numel() // 64
+        rows = self.chip_rows(cursor0, n)
+        plan = None
+        gate_cells = n * self.G
+        if max_rows is not None:
+            plan = N.pack_plan(self.shape, n, start_row, max_rows)
+            gate_cells = int(plan.span_cells)
+        gate = t.full((gate_cells, 4), -1, dtype=t.int64, device=self.device)
+        dense = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
+        spread = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
+        nxt = t.empty((n, 8), dtype=t.int32, device=self.device)
+        lookup = t.empty((n * self.lookup_cells, 4), dtype=t.int64, device=self.device) if want_lookup else None
+        a = N.WitnessArgs()
+        a.d_blocks, a.d_pre_states, a.n_blocks = blocks.data_ptr(), pre_states.data_ptr(), n
+        a.spread_cursor0, a.d_gate = cursor0, gate.data_ptr()
+        a.d_chip_dense, a.d_chip_spread, a.chip_col_stride = dense.data_ptr(), spread.data_ptr(), dense.shape[1]
+        a.d_next_states = nxt.data_ptr()
+        a.d_lookup = lookup.data_ptr() if want_lookup else None
+        a.flags = flags
+        a.pack = C.pointer(plan) if plan is not None else None
+        self._ok(self.lib.hsw_witness_blocks_ex(self.h, C.byref(a)))
+        return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, lookup=lookup, plan=plan, rows=rows)
 
     def witness_blocks_host(self, blocks, pre_states, cursor0=0, flags=0, pinned=True):
         """Host delivery (hsw_witness_blocks_host): numpy in, numpy out.  With

@@ -95,10 +95,26 @@ typedef struct hsw_shape {
     uint32_t limb_calls_per_block;   /* spread_calls * limbs_per_spread (cursor advance) */
     uint32_t chip_cells_per_block;   /* 2 * limb_calls_per_block */
     uint64_t algorithmic_bytes_per_block; /* (G + chip cells) * 32 + 64 + 32 + 32 */
+    uint32_t mode;                   /* HSW_MODE_* this shape was computed for */
+    uint32_t lookup_cells_per_block; /* entries of the lookup-advice column per block (3,184) */
+    uint32_t gate_calls_per_block;   /* halo2-base assign_region calls per block (the tape length) */
+    uint32_t reserved_;
 } hsw_shape;
+
+/* ---- engine modes ---- */
+#define HSW_MODE_DEFAULT          0u
+/* Also emit the cells halo2-base itself allocates inside the path -- the 4-cell
+ * inner product [limb0, limb1, 2^16, a] of every range_check(a, 32) (760 per
+ * block => G = 69,348) -- and make the lookup-advice column stream available
+ * (what RangeConfig::finalize copies, lib.rs:469: 3,184 cells per block).
+ * These follow halo2-lib v0.2.x (DESIGN.md assumption A3); the fork the
+ * reference pins is not in its tree, so A3 is unpinned.  8-bit spread table only. */
+#define HSW_MODE_HALO2_INTERNALS  1u
 
 /* Fill *out for the given SpreadConfig parameters.  Pure host arithmetic. */
 int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out);
+int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode,
+                       hsw_shape *out);
 
 /* Number of rows every chip column buffer must hold for n_blocks blocks whose
  * first limb call is #spread_cursor0: buffer row 0 is absolute chip row
@@ -110,6 +126,8 @@ uint64_t hsw_chip_rows(const hsw_shape *shape, uint64_t spread_cursor0, uint64_t
  * calls on one engine are issued asynchronously in order on that stream. */
 int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
                       uint32_t num_advice_columns, hsw_engine **out);
+int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
+                         uint32_t num_advice_columns, uint32_t mode, hsw_engine **out);
 void hsw_engine_destroy(hsw_engine *e);
 int hsw_engine_shape(const hsw_engine *e, hsw_shape *out);
 int hsw_engine_synchronize(hsw_engine *e);
@@ -134,6 +152,48 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
                        size_t n_blocks, uint64_t spread_cursor0, void *d_gate,
                        void *d_chip_dense, void *d_chip_spread, size_t chip_col_stride,
                        uint32_t *d_next_states, uint32_t flags);
+
+/* ------------------------------------------------------------------------
+ * Placement adaptor: from streams to FlexGate advice columns.
+ * halo2-lib v0.2.x FlexGate (Vertical strategy) fills ONE advice column after
+ * another: every assign_region call of `len` cells goes to the current column
+ * at the current row, or -- if row + len >= max_rows -- to row 0 of the next
+ * column (assumption A3).  So advice columns are the linear gate stream with a
+ * gap of unused tail rows at every column break.  hsw_pack_plan_query computes
+ * the breaks for n_blocks blocks whose first cell lands at `start_row` of some
+ * column; hsw_witness_blocks_ex applies them while writing.
+ * ------------------------------------------------------------------------ */
+#define HSW_MAX_BREAKS 8
+typedef struct hsw_pack_plan {
+    uint32_t n_breaks;
+    uint32_t columns_touched;            /* 1 + n_breaks */
+    uint64_t break_cell[HSW_MAX_BREAKS]; /* linear stream index of the first cell after break k */
+    uint64_t break_gap[HSW_MAX_BREAKS];  /* unused tail rows of the column that break k closes */
+    uint64_t span_cells;                 /* cells from the first written one to one past the last, gaps included */
+    uint64_t end_row;                    /* row after the last cell in the last column (advice_alloc.1) */
+} hsw_pack_plan;
+int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_row, uint64_t max_rows,
+                        hsw_pack_plan *out);
+/* The assign_region call lengths of one block (1 or 4 each), in stream order:
+ * the tape a shim walks to replay the stream into halo2-base.  lens_out may be
+ * NULL to query the count. */
+int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls);
+
+typedef struct hsw_witness_args {
+    const uint8_t *d_blocks;       /* as hsw_witness_blocks */
+    const uint32_t *d_pre_states;
+    size_t n_blocks;
+    uint64_t spread_cursor0;
+    void *d_gate;                  /* where stream cell 0 lands: column base + start_row cells; columns are
+                                      max_rows cells apart, so hsw_pack_plan.span_cells cells are addressed */
+    void *d_chip_dense, *d_chip_spread;
+    size_t chip_col_stride;
+    uint32_t *d_next_states;
+    void *d_lookup;                /* n_blocks * lookup_cells_per_block cells (HSW_MODE_HALO2_INTERNALS), or NULL */
+    uint32_t flags;                /* HSW_REPR_* | HSW_SKIP_* */
+    const hsw_pack_plan *pack;     /* NULL = plain linear stream */
+} hsw_witness_args;
+int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args);
 
 /* Plain SHA-256 chain pre-pass (what makes the blocks of one message
  * independent; lib.rs:188,236): message m has blocks_per_message consecutive

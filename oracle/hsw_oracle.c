@@ -104,6 +104,9 @@ struct oracle_ctx {
     uint64_t num_limb_sum;        /* spread.rs:26 */
     uint64_t row_offset;          /* spread.rs:27 */
     int check;
+    int internals;                /* emit halo2-base's own range_check cells into the gate stream (A3) */
+    int lookup_bits;              /* RangeConfig lookup_bits (16 at every reference config) */
+    ofe_t *lookup; size_t lookup_cap, lookup_len;   /* the lookup-advice column finalize() fills (A3) */
     ofe_t *gate; size_t gate_cap, gate_len;
     uint8_t *kinds; size_t kinds_cap; int cur_kind;   /* optional per-cell tag stream */
     ofe_t *dense, *spread; size_t col_stride; uint64_t row_base;
@@ -128,8 +131,14 @@ oracle_ctx *oracle_create(int num_bits_lookup, int num_advice_columns, int check
     c->num_bits_lookup = num_bits_lookup;
     c->num_advice_columns = num_advice_columns;
     c->check = check;
+    c->lookup_bits = 16;          /* lib.rs:493, benches/digest.rs:108 LOOKUP_BITS */
     return c;
 }
+void oracle_set_internals(oracle_ctx *c, int on) { c->internals = on; }
+void oracle_set_lookup_output(oracle_ctx *c, ofe_t *lookup, size_t cap) {
+    c->lookup = lookup; c->lookup_cap = cap; c->lookup_len = 0;
+}
+size_t oracle_lookup_len(const oracle_ctx *c) { return c->lookup_len; }
 void oracle_destroy(oracle_ctx *c) { free(c); }
 void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap, ofe_t *dense,
                         ofe_t *spread, size_t col_stride, uint64_t row_base) {
@@ -199,7 +208,29 @@ static void g_assert_equal(oracle_ctx *c, ofe_t a, ofe_t b) {
     c->st.assert_equal++;
     if (c->check && !fe_eq(&a, &b)) ofail(c, "assert_equal violated", a.l[0], b.l[0]);
 }
-/* RangeInstructions::range_check(a, bits): constraint a < 2^bits. */
+/* RangeConfig::enable_lookup: the cell is queued in ctx.cells_to_lookup and
+ * copied into the lookup-advice column by finalize() in queue order (A3). */
+static void r_enable_lookup(oracle_ctx *c, const ofe_t *v) {
+    if (c->check && (!fe_is_u64(v) || (v->l[0] >> c->lookup_bits) != 0))
+        ofail(c, "lookup value outside the range table", v->l[0], (uint64_t)c->lookup_bits);
+    if (c->lookup) {
+        if (c->lookup_len < c->lookup_cap) c->lookup[c->lookup_len] = *v;
+        else ofail(c, "lookup buffer overflow", c->lookup_len, c->lookup_cap);
+    }
+    c->lookup_len++;
+}
+/* RangeInstructions::range_check(a, bits): constraint a < 2^bits.
+ * halo2-lib v0.2.x range_check_simple (ASSUMPTION A3, source absent):
+ *   k = ceil(bits / lookup_bits) limbs of lookup_bits bits;
+ *   k == 1: no new cell, `a` itself is looked up;
+ *   k  > 1: inner_product_left(limbs, [1, B, B^2..]) lays out
+ *           [limb0, limb1, B, s1, limb2, B^2, s2, ...] (1 + 3(k-1) cells, overlapping
+ *           gate rows), s_{k-1} copy-constrained to `a`; every limb is looked up;
+ *   bits % lookup_bits = r > 1: one more row [0, last, 2^(lookup_bits-r), last*2^(..)]
+ *           whose output is looked up (r == 1: the last limb is constrained boolean;
+ *           not reachable from this gadget).
+ * The cells are emitted only with oracle_set_internals(1); the lookup queue and
+ * the range self-check always run. */
 static void r_range_check(oracle_ctx *c, ofe_t a, int bits) {
     if (bits == 16) c->st.range_check16++;
     else if (bits == 32) c->st.range_check32++;
@@ -207,6 +238,34 @@ static void r_range_check(oracle_ctx *c, ofe_t a, int bits) {
     if (c->check) {
         if (!fe_is_u64(&a) || (bits < 64 && (a.l[0] >> bits) != 0))
             ofail(c, "range_check violated", a.l[0], (uint64_t)bits);
+    }
+    const int lb = c->lookup_bits;
+    const int k = (bits + lb - 1) / lb, rem = bits % lb;
+    ofe_t last = a;
+    if (k == 1) {
+        r_enable_lookup(c, &a);
+    } else {
+        ofe_t limbs[8], sum = fe_u64(0);
+        for (int i = 0; i < k && i < 8; i++) limbs[i] = fe_u64((a.l[0] >> (lb * i)) & ((1ULL << lb) - 1));
+        if (c->internals) {
+            sum = limbs[0];
+            c->cur_kind = 1;                                   /* rows overlap: [s, a, b, s'] */
+            cell(c, &limbs[0]);
+            for (int i = 1; i < k; i++) {
+                ofe_t base = fe_u64(1ULL << (lb * i)), prod = fe_mul(&limbs[i], &base);
+                sum = fe_add(&sum, &prod);
+                c->cur_kind = 2;
+                cell(c, &limbs[i]); cell(c, &base); cell(c, &sum);
+            }
+            if (c->check && !fe_eq(&sum, &a)) ofail(c, "range_check decomposition", sum.l[0], a.l[0]);
+        }
+        for (int i = 0; i < k; i++) r_enable_lookup(c, &limbs[i]);
+        last = limbs[k - 1];
+    }
+    if (rem > 1) {
+        ofe_t zero = fe_u64(0), mult = fe_u64(1ULL << (lb - rem)), out = fe_mul(&last, &mult);
+        if (c->internals) { c->cur_kind = 1; cell(c, &zero); cell(c, &last); cell(c, &mult); cell(c, &out); }
+        r_enable_lookup(c, &out);
     }
 }
 

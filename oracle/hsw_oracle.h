@@ -89,6 +89,15 @@ void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap,
  * "tape" a placement adaptor needs, and what the gate-equation property test
  * walks.  Indexed like the gate buffer (reset by oracle_set_outputs). */
 void oracle_set_kinds(oracle_ctx *c, uint8_t *kinds, size_t cap);
+/* ASSUMPTION A3 (halo2-lib v0.2.x internals; source absent from the reference
+ * tree): with internals on, range_check(a, 32) also appends its own 4 cells
+ * [limb0, limb1, 2^16, a] to the gate stream at the call position
+ * (range_check(a, 16) adds none).  Independently, every looked-up cell is
+ * appended to the lookup stream -- the content of the lookup-advice column
+ * that RangeConfig::finalize() fills (lib.rs:469), in enable_lookup order. */
+void oracle_set_internals(oracle_ctx *c, int on);
+void oracle_set_lookup_output(oracle_ctx *c, ofe_t *lookup, size_t cap);
+size_t oracle_lookup_len(const oracle_ctx *c);
 /* Set SpreadConfig.num_limb_sum (row_offset follows: spread.rs:228-231). */
 void oracle_set_cursor(oracle_ctx *c, uint64_t num_limb_sum);
 uint64_t oracle_get_cursor(const oracle_ctx *c);

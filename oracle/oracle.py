@@ -54,6 +54,10 @@ def lib():
                                          C.c_void_p, C.c_size_t, C.c_uint64]
         L.oracle_set_cursor.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_set_kinds.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_set_internals.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_lookup_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_lookup_len.restype = C.c_size_t
+        L.oracle_lookup_len.argtypes = [C.c_void_p]
         L.oracle_get_cursor.restype = C.c_uint64
         L.oracle_get_cursor.argtypes = [C.c_void_p]
         L.oracle_gate_len.restype = C.c_size_t
@@ -82,23 +86,48 @@ INIT_STATE = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
                        0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
 
 
-def measure_shape(num_bits_lookup=8, num_advice_columns=2):
-    g, l = C.c_uint64(), C.c_uint64()
-    rc = lib().oracle_measure_shape(num_bits_lookup, num_advice_columns, C.byref(g), C.byref(l))
-    if rc:
-        raise RuntimeError("oracle self-check failed while measuring shape")
-    return int(g.value), int(l.value)
+_shape_cache = {}
+
+
+def measure_shape(num_bits_lookup=8, num_advice_columns=2, internals=False):
+    """(gate cells, limb calls) per block, measured by running one block.  With
+    internals=True the gate count includes halo2-base's range_check cells (A3)."""
+    key = (num_bits_lookup, num_advice_columns, bool(internals))
+    if key not in _shape_cache:
+        L = lib()
+        h = L.oracle_create(num_bits_lookup, num_advice_columns, 1)
+        if not h:
+            raise ValueError("bad shape")
+        L.oracle_set_internals(h, 1 if internals else 0)
+        L.oracle_set_outputs(h, None, 0, None, None, 0, 0)
+        blk = (np.arange(64, dtype=np.uint8) * 37 + 11).astype(np.uint8)
+        nxt = np.zeros(8, dtype=np.uint32)
+        L.oracle_sha256_compression(h, blk.ctypes.data, INIT_STATE.ctypes.data, nxt.ctypes.data)
+        bad = L.oracle_failed(h, None)
+        res = (int(L.oracle_gate_len(h)), int(L.oracle_get_cursor(h)), int(L.oracle_lookup_len(h)))
+        L.oracle_destroy(h)
+        if bad:
+            raise RuntimeError("oracle self-check failed while measuring shape")
+        _shape_cache[key] = res
+    return _shape_cache[key][:2]
+
+
+def lookup_cells_per_block(num_bits_lookup=8, num_advice_columns=2):
+    measure_shape(num_bits_lookup, num_advice_columns, False)
+    return _shape_cache[(num_bits_lookup, num_advice_columns, False)][2]
 
 
 class Oracle:
     """One SpreadConfig + gate context, mirroring the reference's mutable cursors."""
 
-    def __init__(self, num_bits_lookup=8, num_advice_columns=2, check=True):
+    def __init__(self, num_bits_lookup=8, num_advice_columns=2, check=True, internals=False):
         self.L = lib()
         self.bits, self.ncols = num_bits_lookup, num_advice_columns
+        self.internals = bool(internals)
         self.h = self.L.oracle_create(num_bits_lookup, num_advice_columns, 1 if check else 0)
         if not self.h:
             raise ValueError("bad shape: 16 %% num_bits_lookup must be 0 (spread.rs:37)")
+        self.L.oracle_set_internals(self.h, 1 if internals else 0)
         self._keep = None
 
     def close(self):
@@ -131,12 +160,16 @@ class Oracle:
         pre_states = np.ascontiguousarray(pre_states, dtype=np.uint32).reshape(-1, 8)
         n = blocks.shape[0]
         assert pre_states.shape[0] == n
-        G, LC = measure_shape(self.bits, self.ncols)
+        G, LC = measure_shape(self.bits, self.ncols, self.internals)
+        LK = lookup_cells_per_block(self.bits, self.ncols)
         row_base = cursor0 // self.ncols
         rows = (cursor0 % self.ncols + LC * n + self.ncols - 1) // self.ncols
         nxt = np.zeros((n, 8), dtype=np.uint32)
         self.L.oracle_set_cursor(self.h, cursor0)
+        lookup = None
         if want_streams:
+            lookup = np.zeros((n * LK, 4), dtype=np.uint64)
+            self.L.oracle_set_lookup_output(self.h, lookup.ctypes.data, lookup.shape[0])
             gate = np.zeros((n * G, 4), dtype=np.uint64)
             dense = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
             spread = np.zeros((self.ncols, max(rows, 1), 4), dtype=np.uint64)
@@ -144,17 +177,19 @@ class Oracle:
                                       spread.ctypes.data, dense.shape[1], row_base)
         else:
             gate = dense = spread = None
+            self.L.oracle_set_lookup_output(self.h, None, 0)
             self.L.oracle_set_outputs(self.h, None, 0, None, None, 0, 0)
         self.L.oracle_witness_blocks(self.h, blocks.ctypes.data, pre_states.ctypes.data, n, nxt.ctypes.data)
+        self.L.oracle_set_lookup_output(self.h, None, 0)
         self._check()
-        return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, row_base=row_base,
-                    rows=rows, gate_cells_per_block=G, limb_calls_per_block=LC)
+        return dict(gate=gate, dense=dense, spread=spread, lookup=lookup, next_states=nxt, row_base=row_base,
+                    rows=rows, gate_cells_per_block=G, limb_calls_per_block=LC, lookup_cells_per_block=LK)
 
     def digest(self, message: bytes, max_variable_byte_size: int, precomputed_input_len: int = 0,
                want_streams=False, cursor0=None):
         """lib.rs:71-349 on values.  Returns dict(digest, blocks, pre_states, next_states[, streams])."""
         nblk = max_variable_byte_size // 64
-        G, LC = measure_shape(self.bits, self.ncols)
+        G, LC = measure_shape(self.bits, self.ncols, self.internals)
         msg = np.frombuffer(bytes(message), dtype=np.uint8).copy()
         dig = np.zeros(32, dtype=np.uint8)
         blocks = np.zeros((max(nblk, 1), 64), dtype=np.uint8)
@@ -186,12 +221,12 @@ class Oracle:
         return out
 
 
-def gate_tape(num_bits_lookup=8, num_advice_columns=2):
+def gate_tape(num_bits_lookup=8, num_advice_columns=2, internals=False):
     """Per-cell tags of ONE block's gate stream (input independent): uint8 array
     of length G, 0 = load_witness cell, 1..4 = position in a gate row whose
     constraint is x0 + x1*x2 == x3."""
-    G, _ = measure_shape(num_bits_lookup, num_advice_columns)
-    o = Oracle(num_bits_lookup, num_advice_columns, check=True)
+    G, _ = measure_shape(num_bits_lookup, num_advice_columns, internals)
+    o = Oracle(num_bits_lookup, num_advice_columns, check=True, internals=internals)
     kinds = np.zeros(G, dtype=np.uint8)
     o.L.oracle_set_outputs(o.h, None, 0, None, None, 0, 0)
     o.L.oracle_set_kinds(o.h, kinds.ctypes.data, G)

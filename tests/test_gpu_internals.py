@@ -1,0 +1,104 @@
+"""Placement adaptor on the GPU: HSW_MODE_HALO2_INTERNALS gate
+stream (range_check(32) cells included), the lookup-advice column stream, and
+FlexGate column packing -- bit-exact against the oracle and a Python model of
+the packing rule.  All of it rests on assumption A3."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 256, (n, 64), dtype=np.uint8),
+            rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def eng_int(hsw):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    e = hsw.WitnessEngine(0, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("mont", [False, True])
+def test_internals_stream_and_lookup_column(eng_int, oracle, hsw, mont):
+    import torch
+    blocks, pre = _inputs(4, 77)
+    blocks[0] = 0xFF
+    pre[0] = 0xFFFFFFFF
+    ref = oracle.Oracle(8, 2, check=True, internals=True).witness_blocks(blocks, pre, cursor0=2)
+    assert eng_int.G == 69348 == ref["gate_cells_per_block"] and eng_int.lookup_cells == 3184
+    out = eng_int.witness_blocks_ex(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                                    cursor0=2, want_lookup=True, flags=hsw.HSW_REPR_MONTGOMERY if mont else 0)
+    eng_int.synchronize()
+    conv = oracle.to_montgomery if mont else (lambda x: x)
+    g = out["gate"].cpu().numpy().view(np.uint64)
+    exp = conv(ref["gate"])
+    if not np.array_equal(g, exp):
+        bad = np.nonzero((g != exp).any(axis=1))[0]
+        raise AssertionError("gate differs at %d cells, first %d: %s vs %s" % (len(bad), bad[0], g[bad[0]], exp[bad[0]]))
+    assert np.array_equal(out["lookup"].cpu().numpy().view(np.uint64), conv(ref["lookup"]))
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), conv(ref["dense"]))
+    assert np.array_equal(out["next_states"].cpu().numpy().view(np.uint32), ref["next_states"])
+    # every lookup value is a 16-bit range-table entry
+    assert (ref["lookup"][:, 0] < 65536).all() and not ref["lookup"][:, 1:].any()
+
+
+@pytest.mark.parametrize("parts", [1, 4, 16])
+def test_internals_with_split_blocks(eng_int, oracle, parts):
+    import torch
+    eng_int.set_option("parts", parts)
+    try:
+        blocks, pre = _inputs(2, 5 + parts)
+        ref = oracle.Oracle(8, 2, check=True, internals=True).witness_blocks(blocks, pre)
+        out = eng_int.witness_blocks_ex(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                                        want_lookup=True)
+        eng_int.synchronize()
+        assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+        assert np.array_equal(out["lookup"].cpu().numpy().view(np.uint64), ref["lookup"])
+    finally:
+        eng_int.set_option("parts", 0)
+
+
+def _model_positions(lens, n_blocks, start_row, max_rows):
+    col, row, out = 0, start_row, []
+    for _ in range(n_blocks):
+        for ln in lens.tolist():
+            if row + ln >= max_rows:
+                col, row = col + 1, 0
+            out.extend((col, row + k) for k in range(ln))
+            row += ln
+    return out
+
+
+@pytest.mark.parametrize("internals,n,start_row,max_rows", [
+    (True, 3, 1000, 100000),      # one break, in the middle of block 1
+    (True, 4, 69000, 70000),      # a break in every block
+    (False, 5, 17, 40009),        # two breaks inside one block (default mode, 66,308 cells)
+    (True, 16, 4242, 131063)])    # the reference's bench circuit: 16 blocks at k = 17
+def test_flexgate_column_packing(hsw, oracle, eng_int, engine_factory, internals, n, start_row, max_rows):
+    import torch
+    eng = eng_int if internals else engine_factory(8, 2)
+    blocks, pre = _inputs(n, 900 + n)
+    ref = oracle.Oracle(8, 2, check=False, internals=internals).witness_blocks(blocks, pre)
+    out = eng.witness_blocks_ex(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                                start_row=start_row, max_rows=max_rows)
+    eng.synchronize()
+    plan = out["plan"]
+    flat = out["gate"].cpu().numpy().view(np.uint64)
+    assert flat.shape[0] == plan.span_cells
+    lens = hsw._native.gate_tape(eng.shape)
+    pos = _model_positions(lens, n, start_row, max_rows)
+    assert len(pos) == ref["gate"].shape[0]
+    idx = np.array([c * max_rows + r - start_row for c, r in pos], dtype=np.int64)
+    assert idx.max() == plan.span_cells - 1 and len(np.unique(idx)) == len(idx)
+    assert np.array_equal(flat[idx], ref["gate"]), "cells are not where halo2-base's assign_region would put them"
+    # the unused tail rows of every closed column were not touched (buffer was pre-filled with -1)
+    mask = np.ones(flat.shape[0], dtype=bool)
+    mask[idx] = False
+    assert (flat[mask] == np.uint64(2**64 - 1)).all()
+    assert plan.columns_touched == max(c for c, _ in pos) + 1
