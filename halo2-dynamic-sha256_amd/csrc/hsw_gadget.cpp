@@ -203,6 +203,27 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         off += plans[i].max_variable_round;
     }
     h_offsets[n] = (uint32_t)off;
+    // The plain SHA chain (pre-state of every block, lib.rs:188,236) is the only serial
+    // part: ~4 us per block on one GPU lane, ~0.4 us on the host.  A small batch (one
+    // digest of the bench circuit is 16 blocks) is chained here, next to the prefix
+    // pre-hash the reference also does on the CPU (lib.rs:153-160), which saves a
+    // dependent kernel launch; a big batch uses hsw_chain_var_kernel, one lane per message.
+    // Either way the witness cells -- and the next_states the digest is read from -- come
+    // from the GPU.
+    const bool host_chain = batch_blocks <= 2048;
+    std::vector<uint32_t> h_pre;
+    if (host_chain) {
+        h_pre.resize(batch_blocks * 8 ? batch_blocks * 8 : 1);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t st[8];
+            std::memcpy(st, plans[i].init_state, 32);
+            for (size_t j = 0; j < plans[i].max_variable_round; j++) {
+                const size_t b = h_offsets[i] + j;
+                std::memcpy(&h_pre[8 * b], st, 32);
+                plain_compress(st, h_blocks.data() + 64 * b);
+            }
+        }
+    }
 
     // ---- device: chain pre-pass + ONE expansion launch for the whole batch ----
     hipStream_t stream = nullptr;
@@ -220,11 +241,15 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     int rc = HSW_OK;
     do {
         if (batch_blocks == 0) break;
-        if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
         if ((he = hipMemcpyAsync(d_blk, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-        if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-        if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-        if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
+        if (host_chain) {
+            if ((he = hipMemcpyAsync(d_pre, h_pre.data(), batch_blocks * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        } else {
+            if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
+            if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+            if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+            if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
+        }
         const size_t G = ctx.shape.gate_cells_per_block;
         // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
         // Column buffers are addressed from absolute row 0 (cursor origin of the context).
@@ -238,7 +263,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         he = hipStreamSynchronize(stream);
     } while (0);
-    (void)hipFree(d_off);
+    if (d_off) (void)hipFree(d_off);
     if (rc != HSW_OK) return rc;
     if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
 

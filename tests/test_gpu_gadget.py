@@ -118,3 +118,18 @@ def test_gadget_montgomery_repr(engine_factory, hsw, oracle):
     assert np.array_equal(st["gate"], oracle.to_montgomery(ref["gate"]))
     assert np.array_equal(st["dense"], oracle.to_montgomery(ref["dense"]))
     cfg.close()
+
+
+def test_large_batch_uses_gpu_chain_and_matches(engine_factory, hsw):
+    """> 2,048 blocks in one batch: the ragged GPU chain kernel path (small batches chain on the host)."""
+    eng = engine_factory(8, 2)
+    rng = np.random.default_rng(21)
+    n = 700
+    maxes = [192 if i % 3 else 256 for i in range(n)]          # 3- and 4-block hashes, 2,334 blocks
+    msgs = [rng.integers(0, 256, int(rng.integers(0, mx - 9)), dtype=np.uint8).tobytes() for mx in maxes]
+    cfg = hsw.Sha256DynamicConfig(eng, maxes, False)
+    rs = cfg.digest_batch(msgs)
+    assert sum(r.n_blocks for r in rs) > 2048
+    for m, r in zip(msgs, rs):
+        assert r.output_bytes == hashlib.sha256(m).digest()
+    cfg.close()
