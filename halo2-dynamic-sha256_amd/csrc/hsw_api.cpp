@@ -83,20 +83,21 @@ int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSucc
 // Tile shape and waves per block (tuning only; results never change).
 //  * tile: cells per contiguous run of one unit.  Measured on MI355X (tools/ab.py,
 //    interleaved in one process, 4,096 blocks): canonical output is ~3 % faster
-//    with 64-cell tiles and 4 waves per block than with 32-cell tiles and one
-//    wave; Montgomery output (ALU-heavier write-out) prefers 32-cell tiles.
+//    with [32 rows][64 cells] tiles and 4 waves per block than with [64][32] and
+//    one wave; Montgomery output ~5 % faster with [16][128] tiles and 4 waves.
 //  * parts: a block is 64 + 48 + ... independent units; one wave can expand all
 //    of them (lane = unit) or they can be dealt to 2..16 waves.  Small batches
 //    (e.g. the 16-block message of BASELINE configs[1]) need the split to
 //    occupy 256 CUs.
 int choose_tile(const hsw_engine *e, bool mont) {
-    if (e->tile > 0) return (e->limbs == 2) ? e->tile : 32;     // wide tiles are built for 8-bit tables only
-    return (e->limbs == 2 && !mont) ? 64 : 32;
+    if (e->limbs != 2) return 32;                 // wide tiles are built for the 8-bit table only
+    if (e->tile > 0) return e->tile;
+    return mont ? 128 : 64;
 }
 int choose_parts(const hsw_engine *e, size_t n_blocks, int tile) {
     const int min_parts = tile / 32;              // a T-cell tile has 64*32/T rows
     if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
-    int parts = tile == 64 ? 4 : min_parts;
+    int parts = tile >= 64 ? 4 : min_parts;
     while (parts < 16 && n_blocks * (size_t)parts < 2048) parts *= 2;
     return parts;
 }

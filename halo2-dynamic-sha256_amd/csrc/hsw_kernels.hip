@@ -98,27 +98,15 @@ DEV u32 even_bits(u32 x) {
 // ---------------------------------------------------------- Montgomery form
 // HSW_REPR_MONTGOMERY: a cell holds x * 2^256 mod p, halo2curves' in-memory Fr.
 // For x = lo + hi*2^32 < 2^64:  x*R mod p = lo*R + hi*R32 (mod p) with the
-// constants R = 2^256 mod p and R32 = 2^288 mod p, reduced by one Barrett step:
-// t < 2^288, q^ = floor((t >> 224) * floor(2^288/p) / 2^64) is q, q-1 or q-2,
-// so r = t - q^ p < 3p < 2^256 and at most two subtractions of p remain.
+// constants R = 2^256 mod p (~0.29 p) and R32 = 2^288 mod p (~0.14 p), so
+// t = lo*R + hi*R32 < 0.43 * 2^32 * p: the quotient fits 32 bits, and one
+// Barrett step with mu = floor(2^288/p) on the top 64 bits of t gives q^ = q or
+// q - 1 (t/p - th*mu/2^64 < 2^-29 + 0.43), i.e. r = t - q^ p < 2p: exactly one
+// conditional subtraction.  32-bit limbs with explicit carry chains
+// (v_addc_co / v_subb_co): the u64 formulation cost 316 instructions per cell,
+// this one ~170.
 struct Fe8 { u32 l[8]; };
 #define HSW_MU 0x54a474626ull      /* floor(2^288 / p) */
-
-DEV Fe8 fe_sub_p_if_geq(const Fe8 &a) {
-    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
-    Fe8 s;
-    long long br = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const long long d = (long long)a.l[j] - (long long)P[j] + br;
-        s.l[j] = (u32)d;
-        br = d >> 32;                          // 0 or -1
-    }
-    Fe8 o;
-#pragma unroll
-    for (int j = 0; j < 8; j++) o.l[j] = br ? a.l[j] : s.l[j];
-    return o;
-}
 
 template <bool HAS_HI>
 DEV Fe8 mont_from_u64(u32 lo, u32 hi) {
@@ -128,52 +116,57 @@ DEV Fe8 mont_from_u64(u32 lo, u32 hi) {
     const u32 R32[8] = {0x15b8b9dau, 0x93e78865u, 0xb05ea154u, 0x16df2426u,      // 2^288 mod p
                         0x302ab839u, 0x1271b743u, 0xec6c226eu, 0x06bc037eu};
     u32 t[9];
-    u64 c = 0;
+    u32 cy;
+    {   // t = lo * R: low halves at limb j, high halves at limb j + 1
+        u32 h[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { c += (u64)lo * RR[j]; t[j] = (u32)c; c >>= 32; }
-    t[8] = (u32)c;
-    if (HAS_HI) {
-        u32 t2[9];
-        c = 0;
+        for (int j = 0; j < 8; j++) { t[j] = lo * RR[j]; h[j] = __umulhi(lo, RR[j]); }
+        cy = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { c += (u64)hi * R32[j]; t2[j] = (u32)c; c >>= 32; }
-        t2[8] = (u32)c;
-        c = 0;
+        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h[j - 1], cy, &cy);
+        t[8] = h[7] + cy;
+    }
+    if (HAS_HI) {   // t += hi * R32
+        u32 l2[8], h2[8];
 #pragma unroll
-        for (int j = 0; j < 9; j++) { c += (u64)t[j] + t2[j]; t[j] = (u32)c; c >>= 32; }
+        for (int j = 0; j < 8; j++) { l2[j] = hi * R32[j]; h2[j] = __umulhi(hi, R32[j]); }
+        cy = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = __builtin_addc(t[j], l2[j], cy, &cy);
+        t[8] += cy;
+        cy = 0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h2[j - 1], cy, &cy);
+        t[8] += h2[7] + cy;
     }
     const u64 th = ((u64)t[8] << 32) | t[7];
-    const u64 q = __umul64hi(th, HSW_MU);      // < 2^35
-    const u32 q_lo = (u32)q, q_hi = (u32)(q >> 32);
-    // r = (t - q*p) mod 2^256  (the true value is < 3p < 2^256)
-    Fe8 r;
-    u64 ca = 0, cb = 0;
-    long long br = 0;
+    const u32 q = (u32)__umul64hi(th, HSW_MU);            // < 0.43 * 2^32
+    // r = (t - q*p) mod 2^256 (the true value is < 2p < 2^256)
+    u32 ql[8], qh[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        ca += (u64)q_lo * P[j];                                   // limb j of q_lo * p
-        const u32 qp = (u32)ca; ca >>= 32;
-        u64 sum = (u64)qp;
-        if (j >= 1) { cb += (u64)q_hi * P[j - 1]; sum += (u32)cb; cb >>= 32; }   // + limb j-1 of q_hi * p
-        const long long d = (long long)t[j] - (long long)sum + br;    // sum < 2^33
-        r.l[j] = (u32)d;
-        br = d >> 32;
-    }
-    r = fe_sub_p_if_geq(r);
-    r = fe_sub_p_if_geq(r);
+    for (int j = 0; j < 8; j++) { ql[j] = q * P[j]; qh[j] = __umulhi(q, P[j]); }
+    Fe8 r;
+    u32 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = __builtin_subc(t[j], ql[j], br, &br);
+    br = 0;
+#pragma unroll
+    for (int j = 1; j < 8; j++) r.l[j] = __builtin_subc(r.l[j], qh[j - 1], br, &br);
+    u32 sub[8];
+    br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sub[j] = __builtin_subc(r.l[j], P[j], br, &br);
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = br ? r.l[j] : sub[j];
     return r;
 }
 // p - m for a non-zero Montgomery-form m
 DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
     const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
     Fe8 o;
-    long long br = 0;
+    u32 br = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const long long d = (long long)P[j] - (long long)m.l[j] + br;
-        o.l[j] = (u32)d;
-        br = d >> 32;
-    }
+    for (int j = 0; j < 8; j++) o.l[j] = __builtin_subc(P[j], m.l[j], br, &br);
     return o;
 }
 
