@@ -989,6 +989,8 @@ hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t
         case 1: return launch_expand_L<1>(p, tile, stream);
         case 2: return launch_expand_L<2>(p, tile, stream);
         case 4: return launch_expand_L<4>(p, tile, stream);
+        case 8: return launch_expand_L<8>(p, tile, stream);
+        case 16: return launch_expand_L<16>(p, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

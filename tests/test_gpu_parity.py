@@ -35,7 +35,8 @@ def _assert_same(gpu, ref):
     assert np.array_equal(gpu["next_states"].view(np.uint32), ref["next_states"]), "next states differ"
 
 
-@pytest.mark.parametrize("bits,ncols", [(8, 2), (16, 1), (4, 3), (8, 1), (8, 5), (16, 2), (4, 2)])
+@pytest.mark.parametrize("bits,ncols", [(8, 2), (16, 1), (4, 3), (8, 1), (8, 5), (16, 2), (4, 2), (2, 2), (1, 3),
+                                        (2, 7), (1, 16)])
 def test_random_blocks_all_shapes(engine_factory, oracle, bits, ncols):
     eng = engine_factory(bits, ncols)
     blocks, pre = _rand_inputs(5, 100 + bits * 10 + ncols)
@@ -217,7 +218,7 @@ def test_argument_errors(engine_factory, hsw):
     assert b"" != lib.hsw_last_error(eng.h)
 
 
-@pytest.mark.parametrize("bits,ncols,cursor0", [(8, 2, 0), (16, 1, 0), (4, 3, 5), (8, 2, 4121)])
+@pytest.mark.parametrize("bits,ncols,cursor0", [(8, 2, 0), (16, 1, 0), (4, 3, 5), (8, 2, 4121), (2, 2, 1), (1, 5, 0)])
 def test_montgomery_representation(engine_factory, oracle, hsw, bits, ncols, cursor0):
     """HSW_REPR_MONTGOMERY: every cell is x * 2^256 mod p (halo2curves' in-memory
     Fr).  Checked against the oracle's canonical streams converted by a generic
