@@ -1,0 +1,179 @@
+//! Raw bindings of `include/hsw.h` (ABI version 1).  One item per C declaration;
+//! struct layouts are `#[repr(C)]` mirrors.  Not compiled in the build image.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct hsw_engine { _private: [u8; 0] }
+#[repr(C)] pub struct hsw_gadget { _private: [u8; 0] }
+
+pub const HSW_OK: c_int = 0;
+pub const HSW_ERR_INVALID_ARG: c_int = 1;
+pub const HSW_ERR_SHAPE: c_int = 2;
+pub const HSW_ERR_NO_DEVICE: c_int = 3;
+pub const HSW_ERR_HIP: c_int = 4;
+pub const HSW_ERR_UNSUPPORTED: c_int = 5;
+pub const HSW_ERR_TOO_LARGE: c_int = 6;
+pub const HSW_ERR_NOMEM: c_int = 7;
+
+pub const HSW_REPR_CANONICAL: u32 = 0;
+pub const HSW_REPR_MONTGOMERY: u32 = 1;
+pub const HSW_SKIP_GATE: u32 = 2;
+pub const HSW_SKIP_CHIP: u32 = 4;
+pub const HSW_HOST_REGISTER: u32 = 8;
+pub const HSW_MODE_DEFAULT: u32 = 0;
+pub const HSW_MODE_HALO2_INTERNALS: u32 = 1;
+pub const HSW_MAX_BREAKS: usize = 8;
+pub const HSW_CELL_BYTES: usize = 32;
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_shape {
+    pub num_bits_lookup: u32,
+    pub num_advice_columns: u32,
+    pub limbs_per_spread: u32,
+    pub cells_per_spread: u32,
+    pub cells_per_state_spread: u32,
+    pub cells_per_sigma: u32,
+    pub cells_per_ch: u32,
+    pub cells_per_maj: u32,
+    pub cells_per_sched_step: u32,
+    pub cells_per_round: u32,
+    pub off_words: u32,
+    pub off_msg_spread: u32,
+    pub off_sched: u32,
+    pub off_state_spread: u32,
+    pub off_rounds: u32,
+    pub off_feed: u32,
+    pub gate_cells_per_block: u32,
+    pub spread_calls_per_block: u32,
+    pub limb_calls_per_block: u32,
+    pub chip_cells_per_block: u32,
+    pub algorithmic_bytes_per_block: u64,
+    pub mode: u32,
+    pub lookup_cells_per_block: u32,
+    pub gate_calls_per_block: u32,
+    pub reserved_: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct hsw_pack_plan {
+    pub n_breaks: u32,
+    pub columns_touched: u32,
+    pub break_cell: [u64; HSW_MAX_BREAKS],
+    pub break_gap: [u64; HSW_MAX_BREAKS],
+    pub span_cells: u64,
+    pub end_row: u64,
+}
+
+#[repr(C)]
+pub struct hsw_witness_args {
+    pub d_blocks: *const u8,
+    pub d_pre_states: *const u32,
+    pub n_blocks: usize,
+    pub spread_cursor0: u64,
+    pub d_gate: *mut c_void,
+    pub d_chip_dense: *mut c_void,
+    pub d_chip_spread: *mut c_void,
+    pub chip_col_stride: usize,
+    pub d_next_states: *mut u32,
+    pub d_lookup: *mut c_void,
+    pub flags: u32,
+    pub pack: *const hsw_pack_plan,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_digest_info {
+    pub num_round: usize,
+    pub precomputed_round: usize,
+    pub target_round: usize,
+    pub n_blocks: usize,
+}
+
+/// `AssignedHashResult` (reference src/lib.rs:31-36) on values.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct hsw_hash_result {
+    pub input_len: u64,
+    pub first_block: usize,
+    pub n_blocks: usize,
+    pub spread_cursor0: u64,
+    pub num_round: usize,
+    pub target_round: usize,
+    pub output_bytes: [u8; 32],
+}
+
+#[repr(C)]
+pub struct hsw_gadget_view {
+    pub d_gate: *mut c_void,
+    pub d_chip_dense: *mut c_void,
+    pub d_chip_spread: *mut c_void,
+    pub d_next_states: *mut u32,
+    pub chip_col_stride: usize,
+    pub blocks_done: usize,
+    pub capacity_blocks: usize,
+    pub num_limb_sum: u64,
+    pub cur_hash_idx: usize,
+}
+
+extern "C" {
+    pub fn hsw_abi_version() -> u32;
+    pub fn hsw_strerror(status: c_int) -> *const c_char;
+    pub fn hsw_last_error(e: *const hsw_engine) -> *const c_char;
+
+    pub fn hsw_shape_query(num_bits_lookup: u32, num_advice_columns: u32, out: *mut hsw_shape) -> c_int;
+    pub fn hsw_shape_query_ex(num_bits_lookup: u32, num_advice_columns: u32, mode: u32, out: *mut hsw_shape) -> c_int;
+    pub fn hsw_chip_rows(shape: *const hsw_shape, spread_cursor0: u64, n_blocks: u64) -> u64;
+
+    pub fn hsw_engine_create(device: c_int, hip_stream: *mut c_void, num_bits_lookup: u32,
+                             num_advice_columns: u32, out: *mut *mut hsw_engine) -> c_int;
+    pub fn hsw_engine_create_ex(device: c_int, hip_stream: *mut c_void, num_bits_lookup: u32,
+                                num_advice_columns: u32, mode: u32, out: *mut *mut hsw_engine) -> c_int;
+    pub fn hsw_engine_destroy(e: *mut hsw_engine);
+    pub fn hsw_engine_shape(e: *const hsw_engine, out: *mut hsw_shape) -> c_int;
+    pub fn hsw_engine_synchronize(e: *mut hsw_engine) -> c_int;
+    pub fn hsw_engine_stream(e: *const hsw_engine, hip_stream: *mut *mut c_void, device: *mut c_int) -> c_int;
+    pub fn hsw_engine_set_option(e: *mut hsw_engine, name: *const c_char, value: i64) -> c_int;
+
+    /// Replaces the block loop of reference src/lib.rs:180-238 over src/compression.rs:19-25.
+    pub fn hsw_witness_blocks(e: *mut hsw_engine, d_blocks: *const u8, d_pre_states: *const u32,
+                              n_blocks: usize, spread_cursor0: u64, d_gate: *mut c_void,
+                              d_chip_dense: *mut c_void, d_chip_spread: *mut c_void,
+                              chip_col_stride: usize, d_next_states: *mut u32, flags: u32) -> c_int;
+    pub fn hsw_witness_blocks_ex(e: *mut hsw_engine, args: *const hsw_witness_args) -> c_int;
+    pub fn hsw_witness_blocks_host(e: *mut hsw_engine, blocks: *const u8, pre_states: *const u32,
+                                   n_blocks: usize, spread_cursor0: u64, gate: *mut c_void,
+                                   chip_dense: *mut c_void, chip_spread: *mut c_void,
+                                   chip_col_stride: usize, next_states: *mut u32, flags: u32) -> c_int;
+    pub fn hsw_sha256_chain(e: *mut hsw_engine, d_blocks: *const u8, n_messages: usize,
+                            blocks_per_message: usize, d_init_states: *const u32,
+                            d_pre_states: *mut u32) -> c_int;
+
+    pub fn hsw_pack_plan_query(shape: *const hsw_shape, n_blocks: usize, start_row: u64, max_rows: u64,
+                               out: *mut hsw_pack_plan) -> c_int;
+    pub fn hsw_gate_tape(shape: *const hsw_shape, lens_out: *mut u8, cap: usize, n_calls: *mut usize) -> c_int;
+
+    pub fn hsw_digest_prepare(input: *const u8, input_len: usize, precomputed_input_len: usize,
+                              max_variable_byte_size: usize, blocks_out: *mut u8,
+                              init_state_out: *mut u32, info: *mut hsw_digest_info) -> c_int;
+    pub fn hsw_gadget_create(e: *mut hsw_engine, max_variable_byte_sizes: *const usize, n_hashes: usize,
+                             is_input_range_check: c_int, out: *mut *mut hsw_gadget) -> c_int;
+    pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
+    pub fn hsw_gadget_digest(g: *mut hsw_gadget, input: *const u8, input_len: usize,
+                             precomputed_input_len: usize, result: *mut hsw_hash_result) -> c_int;
+    pub fn hsw_gadget_digest_batch(g: *mut hsw_gadget, n: usize, inputs: *const *const u8,
+                                   input_lens: *const usize, precomputed_input_lens: *const usize,
+                                   results: *mut hsw_hash_result) -> c_int;
+    pub fn hsw_gadget_streams(g: *mut hsw_gadget, view: *mut hsw_gadget_view) -> c_int;
+    pub fn hsw_gadget_input_bytes(g: *mut hsw_gadget, hash_idx: usize, out: *mut u8, cap: usize,
+                                  len: *mut usize) -> c_int;
+    pub fn hsw_gadget_set_repr(g: *mut hsw_gadget, repr: u32) -> c_int;
+
+    pub fn hsw_download(e: *mut hsw_engine, host_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn hsw_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn hsw_host_free(p: *mut c_void);
+    pub fn hsw_fill_calibrate(e: *mut hsw_engine, d_buf: *mut c_void, bytes: usize, ms: *mut f32) -> c_int;
+    pub fn hsw_last_kernel_ms(e: *mut hsw_engine, ms: *mut f32) -> c_int;
+    pub fn hsw_set_timing(e: *mut hsw_engine, enabled: c_int) -> c_int;
+}

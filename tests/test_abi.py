@@ -104,3 +104,11 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "hsw_oracle" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def test_rust_binding_source_lists_every_symbol():
+    """rust/hsw-sys (source only -- no Rust toolchain here) must declare every
+    function include/hsw.h declares, so the two cannot drift silently."""
+    rs = open(os.path.join(ROOT, "rust", "hsw-sys", "src", "lib.rs")).read()
+    bound = set(re.findall(r"pub fn (hsw_[a-z0-9_]+)\s*\(", rs))
+    assert bound == set(_declared_functions())
