@@ -95,11 +95,11 @@ int choose_tile(const hsw_engine *e, bool mont) {
     return mont ? 128 : 64;
 }
 int choose_parts(const hsw_engine *e, size_t n_blocks, int tile) {
-    const int min_parts = tile / 32;              // a T-cell tile has 64*32/T rows
+    const int min_parts = tile / 32;              // a T-cell tile has 64*32/T rows: [64][32] [32][64] [16][128]
     if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
     int parts = tile >= 64 ? 4 : min_parts;
     while (parts < 16 && n_blocks * (size_t)parts < 2048) parts *= 2;
-    return parts;
+    return parts < min_parts ? min_parts : parts;
 }
 
 // Makes the engine's device current for the scope of one call.
@@ -249,8 +249,8 @@ int hsw_engine_synchronize(hsw_engine *e) {
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
     if (!e || !name) return HSW_ERR_INVALID_ARG;
     if (std::strcmp(name, "parts") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
-            return set_err(e, HSW_ERR_INVALID_ARG, "parts must be 0 (auto), 1, 2, 4, 8 or 16");
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
+            return set_err(e, HSW_ERR_INVALID_ARG, "parts must be 0 (auto), 1, 2, 4, 8, 16 or 32");
         e->parts = (int)value;
         return HSW_OK;
     }

@@ -206,21 +206,21 @@ struct Em {
 };
 
 // Compile-time emission cursor: POS = cells already in the current tile, FL =
-// tiles flushed so far in this phase, N0/N1 = tile positions (0..63 / 64..127)
-// holding a field negation.
-template <int POS, int FL, u64 N0, u64 N1>
+// tiles flushed so far in this phase, NA..ND = the (at most four: ch has four per
+// round, compression.rs:320-335) tile positions holding a field negation, -1 = none.
+template <int POS, int FL, int NA = -1, int NB = -1, int NC = -1, int ND = -1>
 struct Cur {
     static constexpr int pos = POS, fl = FL;
-    static constexpr u64 n0 = N0, n1 = N1;
+    static constexpr int na = NA, nb = NB, nc = NC, nd = ND;
 };
-using CurStart = Cur<0, 0, 0ull, 0ull>;
+using CurStart = Cur<0, 0>;
 
 // Transpose `ncells` tile columns out to HBM: row r goes to cells
 // [cell_base + r*unit_cells + seg, +ncells).  Canonical form: lane pairs cover one
 // 32-byte cell (low / high 16 bytes), so a wave-wide store instruction writes
 // 1 KiB contiguous.  Montgomery form: one lane per cell, two 16-byte stores.
 template <class EM>
-DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
+DEV void flush_tile(const EM &em, u32 ncells, u32 seg, int na, int nb, int nc, int nd) {
     constexpr int T = EM::TILE;
     __syncthreads();
     const u32 lane = threadIdx.x;
@@ -232,9 +232,9 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
                 const u32 p = i - r * ncells;
                 const u64 v = em.tile[r * (T + 1) + p];
                 Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
-                if ((neg0 | neg1) != 0ull) {
-                    const u64 mword = (T > 64 && p >= 64u) ? neg1 : neg0;
-                    if (((mword >> (p & 63u)) & 1ull) && v != 0ull) m = fe_neg_nonzero(m);
+                if (na >= 0) {                        // compile-time: most tiles hold no neg cell
+                    const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
+                    if (isneg && v != 0ull) m = fe_neg_nonzero(m);
                 }
                 const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
                 uint4 *dst = em.out + ((size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)) * 2u;
@@ -256,9 +256,9 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, u64 neg0, u64 neg1) {
                 o.y = h ? 0u : hi;
                 o.z = 0u;
                 o.w = 0u;
-                if ((neg0 | neg1) != 0ull) {          // compile-time: most tiles hold no neg cell
-                    const u64 mword = (T > 64 && p >= 64u) ? neg1 : neg0;
-                    if (((mword >> (p & 63u)) & 1ull) && v != 0ull) {
+                if (na >= 0) {                        // compile-time: most tiles hold no neg cell
+                    const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
+                    if (isneg && v != 0ull) {
                         // cell holds p - x (neg gate, compression.rs:320-321), x <= 0x55555555
                         o.x = h ? HSW_P4 : (HSW_P0 - lo);
                         o.y = h ? HSW_P5 : HSW_P1;
@@ -278,47 +278,46 @@ template <class EM, class C>
 DEV auto emit(C, EM &em, u64 v) {
     em.row[C::pos] = v;
     if constexpr (C::pos + 1 == EM::TILE) {
-        flush_tile(em, EM::TILE, C::fl * EM::TILE, C::n0, C::n1);
-        return Cur<0, C::fl + 1, 0ull, 0ull>{};
+        flush_tile(em, EM::TILE, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
+        return Cur<0, C::fl + 1>{};
     } else {
-        return Cur<C::pos + 1, C::fl, C::n0, C::n1>{};
+        return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd>{};
     }
 }
-template <int POS, u64 N0> struct NegLo { static constexpr u64 v = N0 | (1ull << POS); };
-template <int POS, u64 N1> struct NegHi { static constexpr u64 v = N1 | (1ull << (POS - 64)); };
-// cell whose field value is -x (x small): stored as x, flagged in the cursor
+// cell whose field value is -x (x small): stored as x, its position appended to the cursor's neg list
 template <class EM, class C>
 DEV auto emit_neg(C, EM &em, u64 x) {
-    if constexpr (C::pos < 64) return emit(Cur<C::pos, C::fl, NegLo<C::pos, C::n0>::v, C::n1>{}, em, x);
-    else return emit(Cur<C::pos, C::fl, C::n0, NegHi<C::pos, C::n1>::v>{}, em, x);
+    static_assert(C::nd < 0, "more than four neg cells in one tile");
+    if constexpr (C::na < 0) return emit(Cur<C::pos, C::fl, C::pos>{}, em, x);
+    else if constexpr (C::nb < 0) return emit(Cur<C::pos, C::fl, C::na, C::pos>{}, em, x);
+    else if constexpr (C::nc < 0) return emit(Cur<C::pos, C::fl, C::na, C::nb, C::pos>{}, em, x);
+    else return emit(Cur<C::pos, C::fl, C::na, C::nb, C::nc, C::pos>{}, em, x);
 }
 
-// Unit expanded by this lane in a phase of n_units units split over `parts` waves
-// (same rule as phase_begin; idle lanes shadow the last active one).
+// Units of a phase dealt to `parts` waves: part k expands the contiguous range
+// [k*per, min((k+1)*per, n_units)) with per = ceil(n_units / parts).
+DEV void part_units(u32 part, u32 parts, u32 n_units, u32 &unit_lo, u32 &nrows) {
+    const u32 per = (n_units + parts - 1) / parts;
+    unit_lo = part * per;
+    nrows = unit_lo >= n_units ? 0u : (n_units - unit_lo < per ? n_units - unit_lo : per);
+}
+// Unit expanded by this lane (idle lanes shadow the last active one).
 DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
     const u32 lane = threadIdx.x;
     u32 nrows, unit_lo;
-    if (n_units % parts == 0) { nrows = n_units / parts; unit_lo = part * nrows; }
-    else { nrows = part == 0 ? n_units : 0; unit_lo = 0; }
-    return unit_lo + (lane < nrows ? lane : (nrows ? nrows - 1 : 0));
+    part_units(part, parts, n_units, unit_lo, nrows);
+    return (nrows ? unit_lo : 0u) + (lane < nrows ? lane : (nrows ? nrows - 1 : 0));
 }
 
-// A phase is `n_units` independent units of `unit_cells` gate cells each.  With
-// the block split over `parts` waves, part k expands units [k*n/parts, (k+1)*n/parts)
-// (phases whose unit count is not a multiple of `parts` run on part 0 alone).
+// A phase is `n_units` independent units of `unit_cells` gate cells each.
 // Returns false if this wave has nothing to do in the phase (wave-uniform).
 template <class EM>
 DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
                      u32 call_base, u32 calls_per_unit, u32 lk_base = 0, u32 lk_per_unit = 0) {
     const u32 lane = threadIdx.x;
     u32 nrows, unit_lo;
-    if (n_units % parts == 0) {
-        nrows = n_units / parts;
-        unit_lo = part * nrows;
-    } else {
-        nrows = part == 0 ? n_units : 0;
-        unit_lo = 0;
-    }
+    part_units(part, parts, n_units, unit_lo, nrows);
+    if (nrows == 0) unit_lo = 0;
     em.nrows = nrows;
     em.unit_cells = unit_cells;
     em.cell_base = phase_off + unit_lo * unit_cells;
@@ -414,7 +413,7 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
 
 template <int L, class EM, class C>
 DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
-    if constexpr (C::pos != 0) flush_tile(em, C::pos, C::fl * EM::TILE, C::n0, C::n1);
+    if constexpr (C::pos != 0) flush_tile(em, C::pos, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
     flush_chip<L>(em, p, block_first_limb);
     if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
 }
@@ -911,6 +910,9 @@ hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) 
         case 32: return launch_expand_LTR<L, 32, 64, false>(p, stream);
         case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32, false>(p, stream); else return hipErrorInvalidValue;
         case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16, false>(p, stream); else return hipErrorInvalidValue;
+        // [8][256], [4][512] and [2][768] tiles (8-24 KiB runs) were measured too: they need 8-32 waves
+        // per block, and the redundant chain work then costs more than the longer runs gain
+        // (1.80 / 1.99 / 2.55 ms against 1.72-1.78 ms).
         default: return hipErrorInvalidValue;
     }
 }
