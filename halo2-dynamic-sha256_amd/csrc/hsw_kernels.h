@@ -1,5 +1,5 @@
 // hsw_kernels.h -- internal launch interface between the C ABI (hsw_api.cpp)
-// and the gfx950 kernels (hsw_kernels.hip).  Not part of the public boundary.
+// and the gfx950 kernels (hsw_expand.hpp, hsw_kernels.hip).  Not part of the public boundary.
 #ifndef HSW_KERNELS_H
 #define HSW_KERNELS_H
 
