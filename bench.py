@@ -270,6 +270,31 @@ def main():
         extra["config1_1KiB_message_16_blocks"] = {
             "device_resident_chain_plus_expand": {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt},
         }
+        try:   # the same two launches captured into one HIP graph and replayed
+            gs = torch.cuda.Stream()
+            eng_g = hsw.WitnessEngine(local_rank, 8, 2, stream=gs)
+            with torch.cuda.stream(gs):
+                pg = eng_g.sha256_chain(b16, 1, 16)
+                eng_g.witness_blocks(b16, pg, out=o16)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=gs):
+                pg = eng_g.sha256_chain(b16, 1, 16)
+                eng_g.witness_blocks(b16, pg, out=o16)
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - t1) / reps
+            extra["config1_1KiB_message_16_blocks"]["hip_graph_replay"] = {"ms_per_message": dtr * 1e3,
+                                                                             "blocks_per_s": 16 / dtr}
+            del graph
+            eng_g.close()
+        except Exception as ex:
+            extra["config1_1KiB_message_16_blocks"]["hip_graph_replay"] = {"error": repr(ex)}
         # the same message through the gadget front-end (Sha256DynamicConfig::digest, lib.rs:71-349):
         # host padding + chain, H2D of the blocks, one expansion launch, D2H of the states, sync
         cfg = hsw.Sha256DynamicConfig(eng, [1024] * 64, True)
@@ -337,6 +362,31 @@ def main():
             del gathered
         except Exception as ex:
             extra["allgather"] = {"error": repr(ex)}
+        # The cheaper equivalent: exchange the 96-byte seeds and let every GPU
+        # re-expand all ranks' blocks into its own HBM.  Bounded: 1,024 blocks per rank.
+        try:
+            nb = min(1024, n)
+            counts = [nb] * world
+            allout = eng.alloc_outputs(nb * world, 0)
+            def replicate():
+                sb, sp = sh.allgather_seeds(dist, blocks[:nb], pre[:nb], counts)
+                eng.witness_blocks(sb, sp, cursor0=0, out=allout)
+            replicate()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                replicate()
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = (time.perf_counter() - t1) / reps
+            extra["replicate_by_seed_exchange"] = {
+                "blocks_per_rank": nb, "ms": dt * 1e3, "blocks_per_s_replicated_on_every_gpu": nb * world / dt,
+                "xgmi_bytes_per_block": 96, "note": "every GPU ends with all ranks' witness columns in its own HBM"}
+            del allout
+        except Exception as ex:
+            extra["replicate_by_seed_exchange"] = {"error": repr(ex)}
 
     result = None
     if rank == 0:

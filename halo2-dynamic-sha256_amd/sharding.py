@@ -96,3 +96,30 @@ def allgather_chip(dist, local_cols, cursor0, starts, counts, limb_calls_per_blo
                 continue
             out[c, lo - row0: hi - row0 + 1] = gathered[r, c, lo - wrow0: hi - wrow0 + 1]
     return out
+
+
+def allgather_seeds(dist, local_blocks, local_pre_states, counts, group=None):
+    """All-gather the 96-byte *seeds* of every block (64 message bytes + 8 pre-state
+    words) instead of its 2.39 MB of witness cells.  Every rank can then expand
+    any block range locally (a witness stream is a pure function of its seed and
+    of the closed-form chip cursor), which on xGMI is ~25,000x less traffic than
+    gathering the columns and, with 288 GB of HBM per GPU, lets every GPU hold
+    the complete 8-GPU witness (65,536 blocks = 156 GB) if it needs to.
+    local_blocks: (n_r, 64) uint8; local_pre_states: (n_r, 8) int32; counts[r] = n_r.
+    Returns (blocks (sum n, 64) uint8, pre_states (sum n, 8) int32) in rank order."""
+    import torch
+    world = len(counts)
+    cmax = max(counts)
+    dev = local_blocks.device
+    buf = torch.zeros((cmax, 96), dtype=torch.uint8, device=dev)
+    n = local_blocks.shape[0]
+    if n:
+        buf[:n, :64] = local_blocks
+        buf[:n, 64:] = local_pre_states.contiguous().view(torch.uint8).reshape(n, 32)
+    out = torch.empty((world * cmax, 96), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    parts = [out[r * cmax: r * cmax + counts[r]] for r in range(world)]
+    allseeds = torch.cat(parts, dim=0) if not all(c == cmax for c in counts) else out
+    blocks = allseeds[:, :64].contiguous()
+    pre = allseeds[:, 64:].contiguous().view(torch.int32).reshape(-1, 8)
+    return blocks, pre

@@ -293,3 +293,65 @@ def test_pipelined_host_delivery(engine_factory, oracle, hsw, ncols, n, pinned, 
     assert np.array_equal(got["gate"], ref["gate"])
     assert np.array_equal(got["dense"], ref["dense"]) and np.array_equal(got["spread"], ref["spread"])
     assert np.array_equal(got["next_states"], ref["next_states"])
+
+
+def test_hip_graph_capture_and_replay(hsw, oracle):
+    """The launch path does no allocation / synchronization, so chain + expand can
+    be captured into a HIP graph and replayed on new inputs (launch-bound small
+    batches: BASELINE configs[1], one 16-block message)."""
+    import torch
+    st = torch.cuda.Stream()
+    eng = hsw.WitnessEngine(0, 8, 2, stream=st)
+    rng = np.random.default_rng(404)
+    static_blocks = torch.zeros((16, 64), dtype=torch.uint8, device="cuda")
+    out = eng.alloc_outputs(16)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        pre = eng.sha256_chain(static_blocks, 1, 16)          # warm-up outside capture
+        eng.witness_blocks(static_blocks, pre, out=out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        pre = eng.sha256_chain(static_blocks, 1, 16)
+        eng.witness_blocks(static_blocks, pre, out=out)
+    for trial in range(3):
+        blocks = rng.integers(0, 256, (16, 64), dtype=np.uint8)
+        static_blocks.copy_(torch.from_numpy(blocks))
+        g.replay()
+        torch.cuda.synchronize()
+        st_ = oracle.INIT_STATE.copy()
+        pres = []
+        for b in blocks:
+            pres.append(st_.copy())
+            st_ = oracle.plain_compress(st_, b)
+        ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, np.array(pres))
+        assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"]), trial
+        assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+        assert np.array_equal(out["next_states"].cpu().numpy().view(np.uint32), ref["next_states"])
+    eng.close()
+
+
+def test_two_engines_two_streams_concurrently(hsw, oracle):
+    """One engine per stream (hsw.h threading contract): interleaved launches on two
+    streams, both correct."""
+    import torch
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    e1, e2 = hsw.WitnessEngine(0, 8, 2, stream=s1), hsw.WitnessEngine(0, 8, 3, stream=s2)
+    b1, p1 = _rand_inputs(40, 1)
+    b2, p2 = _rand_inputs(40, 2)
+    t1 = (torch.from_numpy(b1).cuda(), torch.from_numpy(p1.view(np.int32)).cuda())
+    t2 = (torch.from_numpy(b2).cuda(), torch.from_numpy(p2.view(np.int32)).cuda())
+    o1, o2 = e1.alloc_outputs(40), e2.alloc_outputs(40, 5)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        e1.witness_blocks(*t1, out=o1)
+        e2.witness_blocks(*t2, cursor0=5, out=o2)
+    e1.synchronize()
+    e2.synchronize()
+    r1 = oracle.Oracle(8, 2, check=False).witness_blocks(b1, p1)
+    r2 = oracle.Oracle(8, 3, check=False).witness_blocks(b2, p2, cursor0=5)
+    assert np.array_equal(o1["gate"].cpu().numpy().view(np.uint64), r1["gate"])
+    assert np.array_equal(o2["gate"].cpu().numpy().view(np.uint64), r2["gate"])
+    assert np.array_equal(o2["spread"].cpu().numpy().view(np.uint64), r2["spread"])
+    e1.close()
+    e2.close()

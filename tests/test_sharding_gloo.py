@@ -36,6 +36,12 @@ def _worker(rank, world, port, n_blocks, bits, ncols, cursor0, q):
         spread = sh.allgather_chip(dist, torch.from_numpy(w["spread"].view(np.int64)), cursor0, starts,
                                    counts, LC, ncols)
         serial = O.Oracle(bits, ncols, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
+        # seed exchange: 96 bytes per block instead of the columns; every rank re-expands everything
+        sb, sp = sh.allgather_seeds(dist, torch.from_numpy(blocks[s:s + c].copy()),
+                                    torch.from_numpy(pre[s:s + c].view(np.int32).copy()), counts)
+        assert np.array_equal(sb.numpy(), blocks) and np.array_equal(sp.numpy().view(np.uint32), pre)
+        again = O.Oracle(bits, ncols, check=False).witness_blocks(sb.numpy(), sp.numpy().view(np.uint32), cursor0=cursor0)
+        assert np.array_equal(again["gate"], serial["gate"]) and np.array_equal(again["dense"], serial["dense"])
         ok = (np.array_equal(gate.numpy().view(np.uint64), serial["gate"])
               and np.array_equal(dense.numpy().view(np.uint64), serial["dense"])
               and np.array_equal(spread.numpy().view(np.uint64), serial["spread"]))
