@@ -248,6 +248,21 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0:
+        # same batch with cells in Montgomery form (x * 2^256 mod p: halo2curves' in-memory Fr)
+        try:
+            for _ in range(2):
+                eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
+            mm = []
+            for _ in range(5):
+                eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
+                mm.append(eng.last_kernel_ms())
+            m_ms = float(np.median(mm))
+            extra["montgomery_repr"] = {"kernel_ms": m_ms, "blocks_per_s": n / m_ms * 1e3,
+                                        "GBps": alg_bytes * n / m_ms / 1e6, "frac_of_peak": alg_bytes * n / m_ms / 1e6 / HBM_PEAK_GBS}
+            step()      # leave canonical cells in the buffers
+        except Exception as ex:
+            extra["montgomery_repr"] = {"error": repr(ex)}
+    if not args.no_extra and rank == 0:
         # configs[1]: one 1 KiB-class message = 16 chained blocks (1,015 bytes)
         m = bytes(((i * 131 + 7) % 256) for i in range(1015))
         padded = bytearray(m) + b"\x80" + b"\x00" * ((64 - (len(m) + 9) % 64) % 64) + (8 * len(m)).to_bytes(8, "big")

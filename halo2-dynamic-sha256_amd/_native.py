@@ -86,7 +86,7 @@ SYMBOLS = (
     "hsw_gadget_digest", "hsw_gadget_digest_batch", "hsw_gadget_streams", "hsw_gadget_input_bytes",
     "hsw_gadget_set_repr", "hsw_download", "hsw_host_alloc", "hsw_host_free",
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
-    "hsw_witness_blocks_ex",
+    "hsw_witness_blocks_ex", "hsw_spread_table",
 )
 
 
@@ -176,6 +176,8 @@ def lib():
         L.hsw_gate_tape.argtypes = [C.POINTER(Shape), vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.hsw_witness_blocks_ex.restype = C.c_int
         L.hsw_witness_blocks_ex.argtypes = [vp, C.POINTER(WitnessArgs)]
+        L.hsw_spread_table.restype = C.c_int
+        L.hsw_spread_table.argtypes = [C.c_uint32, vp, vp]
         L.hsw_host_alloc.restype = C.c_int
         L.hsw_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
         L.hsw_host_free.restype = None
@@ -216,6 +218,17 @@ def shape_query(num_bits_lookup=8, num_advice_columns=2, mode=HSW_MODE_DEFAULT):
     if rc != HSW_OK:
         raise HswError(rc)
     return s
+
+
+def spread_table(num_bits_lookup=8):
+    """SpreadConfig::load rows (spread.rs:165-194) as two numpy uint64 arrays."""
+    import numpy as np
+    n = 1 << num_bits_lookup
+    d, s = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    rc = lib().hsw_spread_table(num_bits_lookup, d.ctypes.data, s.ctypes.data)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return d, s
 
 
 def gate_tape(shape):

@@ -162,6 +162,17 @@ int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, ui
     return HSW_OK;
 }
 
+int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out) {
+    if (num_bits_lookup == 0 || num_bits_lookup > 16 || 16 % num_bits_lookup != 0) return HSW_ERR_SHAPE;
+    for (uint64_t idx = 0; idx < (1ull << num_bits_lookup); idx++) {              // spread.rs:169-189
+        uint64_t sp = 0;
+        for (int b = 0; b < 16; b++) sp |= ((idx >> b) & 1ull) << (2 * b);        // bit i -> bit 2i (:172-175)
+        if (dense_out) dense_out[idx] = idx;
+        if (spread_out) spread_out[idx] = sp;
+    }
+    return HSW_OK;
+}
+
 uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) {
     if (!s || s->num_advice_columns == 0 || s->limb_calls_per_block == 0) return 0;
     const uint64_t nc = s->num_advice_columns;

@@ -116,6 +116,10 @@ int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_s
 int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode,
                        hsw_shape *out);
 
+/* SpreadConfig::load (spread.rs:165-194): the 2^num_bits_lookup rows
+ * (i, spread(i)) of the lookup table, as u64 values.  Either output may be NULL. */
+int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out);
+
 /* Number of rows every chip column buffer must hold for n_blocks blocks whose
  * first limb call is #spread_cursor0: buffer row 0 is absolute chip row
  * spread_cursor0 / ncols.  Returns 0 on a bad shape. */

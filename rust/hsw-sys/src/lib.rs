@@ -124,6 +124,7 @@ extern "C" {
 
     pub fn hsw_shape_query(num_bits_lookup: u32, num_advice_columns: u32, out: *mut hsw_shape) -> c_int;
     pub fn hsw_shape_query_ex(num_bits_lookup: u32, num_advice_columns: u32, mode: u32, out: *mut hsw_shape) -> c_int;
+    pub fn hsw_spread_table(num_bits_lookup: u32, dense_out: *mut u64, spread_out: *mut u64) -> c_int;
     pub fn hsw_chip_rows(shape: *const hsw_shape, spread_cursor0: u64, n_blocks: u64) -> u64;
 
     pub fn hsw_engine_create(device: c_int, hip_stream: *mut c_void, num_bits_lookup: u32,

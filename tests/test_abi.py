@@ -112,3 +112,13 @@ def test_rust_binding_source_lists_every_symbol():
     rs = open(os.path.join(ROOT, "rust", "hsw-sys", "src", "lib.rs")).read()
     bound = set(re.findall(r"pub fn (hsw_[a-z0-9_]+)\s*\(", rs))
     assert bound == set(_declared_functions())
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4, 8, 16])
+def test_spread_table_matches_oracle(hsw, oracle, bits):
+    """SpreadConfig::load (spread.rs:165-194)."""
+    d, s = hsw._native.spread_table(bits)
+    ref = oracle.spread_table(bits)
+    assert [(int(a), int(b)) for a, b in zip(d, s)] == ref
+    with pytest.raises(hsw.HswError):
+        hsw._native.spread_table(3)
