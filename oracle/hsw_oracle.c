@@ -112,6 +112,8 @@ struct oracle_ctx {
     ofe_t *dense, *spread; size_t col_stride; uint64_t row_base;
     oracle_stats_t st;
     int failed; char msg[256];
+    size_t block_start;            /* gate_len at the start of the current block */
+    oracle_constraints_t *rec;     /* constraint-structure recorder (next block only), or NULL */
 };
 
 static void ofail(oracle_ctx *c, const char *what, uint64_t a, uint64_t b) {
@@ -146,6 +148,10 @@ void oracle_set_outputs(oracle_ctx *c, ofe_t *gate, size_t gate_cap, ofe_t *dens
     c->dense = dense; c->spread = spread; c->col_stride = col_stride; c->row_base = row_base;
 }
 void oracle_set_kinds(oracle_ctx *c, uint8_t *kinds, size_t cap) { c->kinds = kinds; c->kinds_cap = cap; }
+void oracle_record_constraints(oracle_ctx *c, oracle_constraints_t *rec) {
+    if (rec) { rec->n_eq = rec->n_const = rec->n_range = rec->n_chip = rec->n_lookup = 0; }
+    c->rec = rec;
+}
 void oracle_set_cursor(oracle_ctx *c, uint64_t n) {
     c->num_limb_sum = n;
     c->row_offset = n / (uint64_t)c->num_advice_columns;   /* spread.rs:228-231 closed form */
@@ -159,63 +165,114 @@ int oracle_failed(const oracle_ctx *c, const char **msg) {
 }
 
 /* ------------------------------------------------- halo2-base gate mirror */
-/* One advice cell of the gate stream. */
-static inline void cell(oracle_ctx *c, const ofe_t *v) {
+/* An AssignedValue: its value and the cell it lives in.  Cells of the gate
+ * stream are numbered block-relative (0..G-1); cells outside the stream have
+ * negative ids (ORACLE_CELL_*).  A QuantumCell::Constant is an av_t whose cell is
+ * CELL_CONST.  The cell ids are what lets the oracle record the reference's
+ * constraint *structure* (which cells halo2 copy-constrains / fixes), next to
+ * the values. */
+typedef struct { ofe_t v; int64_t cell; } av_t;
+#define CELL_CONST   INT64_MIN
+static inline av_t K(uint64_t x) { av_t r; r.v = fe_u64(x); r.cell = CELL_CONST; return r; }
+static inline av_t ext_cell(uint64_t x, int64_t id) { av_t r; r.v = fe_u64(x); r.cell = id; return r; }
+
+static void rec_eq(oracle_ctx *c, int64_t a, int64_t b) {
+    if (!c->rec) return;
+    oracle_constraints_t *r = c->rec;
+    if (r->eq && r->n_eq < r->eq_cap) { r->eq[2 * r->n_eq] = a; r->eq[2 * r->n_eq + 1] = b; }
+    r->n_eq++;
+}
+static void rec_const(oracle_ctx *c, int64_t cell_id, uint64_t value) {
+    if (!c->rec) return;
+    oracle_constraints_t *r = c->rec;
+    if (r->konst && r->n_const < r->const_cap) { r->konst[2 * r->n_const] = cell_id; r->konst[2 * r->n_const + 1] = (int64_t)value; }
+    r->n_const++;
+}
+static void rec_range(oracle_ctx *c, int64_t cell_id, int bits) {
+    if (!c->rec) return;
+    oracle_constraints_t *r = c->rec;
+    if (r->range && r->n_range < r->range_cap) { r->range[2 * r->n_range] = cell_id; r->range[2 * r->n_range + 1] = bits; }
+    r->n_range++;
+}
+
+/* One advice cell of the gate stream holding QuantumCell q.  Existing(x): the new
+ * cell is copy-constrained to x's cell; Constant(k): fixed to k; Witness: free.
+ * Returns the new cell's block-relative index. */
+static inline int64_t cell(oracle_ctx *c, const av_t *q, int is_witness) {
+    const int64_t idx = (int64_t)(c->gate_len - c->block_start);
     if (c->kinds && c->gate_len < c->kinds_cap) c->kinds[c->gate_len] = (uint8_t)c->cur_kind;
     if (c->cur_kind) c->cur_kind++;       /* 1..4 = position inside a 4-cell gate row */
     if (c->gate) {
-        if (c->gate_len < c->gate_cap) c->gate[c->gate_len] = *v;
+        if (c->gate_len < c->gate_cap) c->gate[c->gate_len] = q->v;
         else ofail(c, "gate buffer overflow", c->gate_len, c->gate_cap);
     }
     c->gate_len++;
     c->st.gate_cells++;
+    if (!is_witness) {
+        if (q->cell == CELL_CONST) rec_const(c, idx, q->v.l[0]);
+        else rec_eq(c, idx, q->cell);
+    }
+    return idx;
+}
+static inline av_t witness_cell(oracle_ctx *c, ofe_t v) {
+    av_t r; r.v = v; r.cell = 0;
+    r.cell = cell(c, &r, 1);
+    return r;
 }
 /* GateInstructions::load_witness -> [v] */
-static ofe_t g_load_witness(oracle_ctx *c, ofe_t v) {
+static av_t g_load_witness(oracle_ctx *c, ofe_t v) {
     c->st.load_witness++;
     c->cur_kind = 0;
-    cell(c, &v);
-    return v;
+    return witness_cell(c, v);
 }
-/* GateInstructions::load_zero: cached in the Context (assumption A2). */
-static ofe_t g_load_zero(oracle_ctx *c) { c->st.load_zero++; return fe_u64(0); }
+/* GateInstructions::load_zero: cached in the Context (assumption A2): one cell
+ * outside the stream, fixed to 0. */
+static av_t g_load_zero(oracle_ctx *c) { c->st.load_zero++; return ext_cell(0, ORACLE_CELL_ZERO); }
 /* GateInstructions::add -> [a, b, 1, a+b] */
-static ofe_t g_add(oracle_ctx *c, ofe_t a, ofe_t b) {
+static av_t g_add(oracle_ctx *c, av_t a, av_t b) {
     c->st.add++;
-    ofe_t one = fe_u64(1), out = fe_add(&a, &b);
+    av_t one = K(1);
     c->cur_kind = 1;
-    cell(c, &a); cell(c, &b); cell(c, &one); cell(c, &out);
-    return out;
+    cell(c, &a, 0); cell(c, &b, 0); cell(c, &one, 0);
+    return witness_cell(c, fe_add(&a.v, &b.v));
 }
 /* GateInstructions::neg -> [a, -a, 1, 0] */
-static ofe_t g_neg(oracle_ctx *c, ofe_t a) {
+static av_t g_neg(oracle_ctx *c, av_t a) {
     c->st.neg++;
-    ofe_t one = fe_u64(1), zero = fe_u64(0), out = fe_neg(&a);
+    av_t one = K(1), zero = K(0);
     c->cur_kind = 1;
-    cell(c, &a); cell(c, &out); cell(c, &one); cell(c, &zero);
+    cell(c, &a, 0);
+    av_t out = witness_cell(c, fe_neg(&a.v));
+    cell(c, &one, 0); cell(c, &zero, 0);
     return out;
 }
 /* GateInstructions::mul_add(a, b, c) = a*b + c -> [c, a, b, out] */
-static ofe_t g_mul_add(oracle_ctx *c, ofe_t a, ofe_t b, ofe_t cc) {
+static av_t g_mul_add(oracle_ctx *c, av_t a, av_t b, av_t cc) {
     c->st.mul_add++;
-    ofe_t ab = fe_mul(&a, &b), out = fe_add(&ab, &cc);
+    ofe_t ab = fe_mul(&a.v, &b.v);
     c->cur_kind = 1;
-    cell(c, &cc); cell(c, &a); cell(c, &b); cell(c, &out);
-    return out;
+    cell(c, &cc, 0); cell(c, &a, 0); cell(c, &b, 0);
+    return witness_cell(c, fe_add(&ab, &cc.v));
 }
 /* GateInstructions::assert_equal: copy constraint only. */
-static void g_assert_equal(oracle_ctx *c, ofe_t a, ofe_t b) {
+static void g_assert_equal(oracle_ctx *c, av_t a, av_t b) {
     c->st.assert_equal++;
-    if (c->check && !fe_eq(&a, &b)) ofail(c, "assert_equal violated", a.l[0], b.l[0]);
+    if (c->check && !fe_eq(&a.v, &b.v)) ofail(c, "assert_equal violated", a.v.l[0], b.v.l[0]);
+    rec_eq(c, a.cell, b.cell);
 }
 /* RangeConfig::enable_lookup: the cell is queued in ctx.cells_to_lookup and
  * copied into the lookup-advice column by finalize() in queue order (A3). */
-static void r_enable_lookup(oracle_ctx *c, const ofe_t *v) {
-    if (c->check && (!fe_is_u64(v) || (v->l[0] >> c->lookup_bits) != 0))
-        ofail(c, "lookup value outside the range table", v->l[0], (uint64_t)c->lookup_bits);
+static void r_enable_lookup(oracle_ctx *c, const av_t *v) {
+    if (c->check && (!fe_is_u64(&v->v) || (v->v.l[0] >> c->lookup_bits) != 0))
+        ofail(c, "lookup value outside the range table", v->v.l[0], (uint64_t)c->lookup_bits);
     if (c->lookup) {
-        if (c->lookup_len < c->lookup_cap) c->lookup[c->lookup_len] = *v;
+        if (c->lookup_len < c->lookup_cap) c->lookup[c->lookup_len] = v->v;
         else ofail(c, "lookup buffer overflow", c->lookup_len, c->lookup_cap);
+    }
+    if (c->rec) {   /* lookup-column entry j is a copy of this cell */
+        oracle_constraints_t *r = c->rec;
+        if (r->lookup_src && r->n_lookup < r->lookup_cap) r->lookup_src[r->n_lookup] = v->cell;
+        r->n_lookup++;
     }
     c->lookup_len++;
 }
@@ -229,42 +286,54 @@ static void r_enable_lookup(oracle_ctx *c, const ofe_t *v) {
  *   bits % lookup_bits = r > 1: one more row [0, last, 2^(lookup_bits-r), last*2^(..)]
  *           whose output is looked up (r == 1: the last limb is constrained boolean;
  *           not reachable from this gadget).
- * The cells are emitted only with oracle_set_internals(1); the lookup queue and
- * the range self-check always run. */
-static void r_range_check(oracle_ctx *c, ofe_t a, int bits) {
+ * The cells are emitted only with oracle_set_internals(1); the lookup queue, the
+ * recorded range bound and the range self-check always run. */
+static void r_range_check(oracle_ctx *c, av_t a, int bits) {
     if (bits == 16) c->st.range_check16++;
     else if (bits == 32) c->st.range_check32++;
     else c->st.range_check_other++;
     if (c->check) {
-        if (!fe_is_u64(&a) || (bits < 64 && (a.l[0] >> bits) != 0))
-            ofail(c, "range_check violated", a.l[0], (uint64_t)bits);
+        if (!fe_is_u64(&a.v) || (bits < 64 && (a.v.l[0] >> bits) != 0))
+            ofail(c, "range_check violated", a.v.l[0], (uint64_t)bits);
     }
+    rec_range(c, a.cell, bits);
     const int lb = c->lookup_bits;
     const int k = (bits + lb - 1) / lb, rem = bits % lb;
-    ofe_t last = a;
+    av_t last = a;
     if (k == 1) {
         r_enable_lookup(c, &a);
     } else {
-        ofe_t limbs[8], sum = fe_u64(0);
-        for (int i = 0; i < k && i < 8; i++) limbs[i] = fe_u64((a.l[0] >> (lb * i)) & ((1ULL << lb) - 1));
+        av_t limbs[8];
+        for (int i = 0; i < k && i < 8; i++) {
+            limbs[i].v = fe_u64((a.v.l[0] >> (lb * i)) & ((1ULL << lb) - 1));
+            limbs[i].cell = ORACLE_CELL_HIDDEN;        /* halo2-base's own witness; a stream cell only with internals */
+        }
         if (c->internals) {
-            sum = limbs[0];
             c->cur_kind = 1;                                   /* rows overlap: [s, a, b, s'] */
-            cell(c, &limbs[0]);
+            limbs[0] = witness_cell(c, limbs[0].v);
+            av_t sum = limbs[0];
             for (int i = 1; i < k; i++) {
-                ofe_t base = fe_u64(1ULL << (lb * i)), prod = fe_mul(&limbs[i], &base);
-                sum = fe_add(&sum, &prod);
+                av_t base = K(1ULL << (lb * i));
+                ofe_t prod = fe_mul(&limbs[i].v, &base.v);
                 c->cur_kind = 2;
-                cell(c, &limbs[i]); cell(c, &base); cell(c, &sum);
+                limbs[i] = witness_cell(c, limbs[i].v);
+                cell(c, &base, 0);
+                sum = witness_cell(c, fe_add(&sum.v, &prod));
             }
-            if (c->check && !fe_eq(&sum, &a)) ofail(c, "range_check decomposition", sum.l[0], a.l[0]);
+            if (c->check && !fe_eq(&sum.v, &a.v)) ofail(c, "range_check decomposition", sum.v.l[0], a.v.l[0]);
+            rec_eq(c, sum.cell, a.cell);                       /* constrain_equal(a, acc) */
         }
         for (int i = 0; i < k; i++) r_enable_lookup(c, &limbs[i]);
         last = limbs[k - 1];
     }
     if (rem > 1) {
-        ofe_t zero = fe_u64(0), mult = fe_u64(1ULL << (lb - rem)), out = fe_mul(&last, &mult);
-        if (c->internals) { c->cur_kind = 1; cell(c, &zero); cell(c, &last); cell(c, &mult); cell(c, &out); }
+        av_t zero = K(0), mult = K(1ULL << (lb - rem));
+        av_t out; out.v = fe_mul(&last.v, &mult.v); out.cell = ORACLE_CELL_HIDDEN;
+        if (c->internals) {
+            c->cur_kind = 1;
+            cell(c, &zero, 0); cell(c, &last, 0); cell(c, &mult, 0);
+            out = witness_cell(c, out.v);
+        }
         r_enable_lookup(c, &out);
     }
 }
@@ -307,63 +376,71 @@ uint64_t oracle_spread_table_entry(uint32_t i) {
 
 /* spread.rs:196-233 spread_limb: two raw region.assign_advice cells at
  * (denses[col], row_offset) / (spreads[col], row_offset), one load_witness. */
-static ofe_t sc_spread_limb(oracle_ctx *c, ofe_t limb) {
+static av_t sc_spread_limb(oracle_ctx *c, av_t limb) {
     c->st.spread_limb_calls++;
     uint64_t column_idx = c->num_limb_sum % (uint64_t)c->num_advice_columns;    /* :202 */
-    ofe_t spread_value = spread_value_of(c, &limb);                              /* :211-218 */
+    ofe_t spread_value = spread_value_of(c, &limb.v);                            /* :211-218 */
     if (c->check) {
         /* the "spread lookup" (spread.rs:56-62): (dense, spread) must be a table row */
-        if (!fe_is_u64(&limb) || limb.l[0] >= (1ULL << c->num_bits_lookup))
-            ofail(c, "spread lookup: dense limb outside table", limb.l[0], 1ULL << c->num_bits_lookup);
-        else if (spread_value.l[0] != oracle_spread_table_entry((uint32_t)limb.l[0]))
-            ofail(c, "spread lookup: spread mismatch", spread_value.l[0], limb.l[0]);
+        if (!fe_is_u64(&limb.v) || limb.v.l[0] >= (1ULL << c->num_bits_lookup))
+            ofail(c, "spread lookup: dense limb outside table", limb.v.l[0], 1ULL << c->num_bits_lookup);
+        else if (spread_value.l[0] != oracle_spread_table_entry((uint32_t)limb.v.l[0]))
+            ofail(c, "spread lookup: spread mismatch", spread_value.l[0], limb.v.l[0]);
     }
     if (c->dense && c->spread) {
         if (c->row_offset < c->row_base || c->row_offset - c->row_base >= c->col_stride)
             ofail(c, "chip row outside buffer", c->row_offset, c->row_base);
         else {
             size_t at = (size_t)column_idx * c->col_stride + (size_t)(c->row_offset - c->row_base);
-            c->dense[at] = limb;                                                 /* :203-208 */
+            c->dense[at] = limb.v;                                               /* :203-208 */
             c->spread[at] = spread_value;                                        /* :219-224 */
         }
     }
     c->st.chip_cells += 2;
-    ofe_t assigned_spread_value = g_load_witness(c, spread_value);               /* :225 */
+    av_t assigned_spread_value = g_load_witness(c, spread_value);                /* :225 */
+    if (c->rec) {   /* :209-210 dense chip cell == limb's cell; :226-227 spread chip cell == the new witness */
+        oracle_constraints_t *r = c->rec;
+        if (r->chip && r->n_chip < r->chip_cap) {
+            r->chip[2 * r->n_chip] = limb.cell;
+            r->chip[2 * r->n_chip + 1] = assigned_spread_value.cell;
+        }
+        r->n_chip++;
+    }
     c->num_limb_sum += 1;                                                        /* :228 */
     if (column_idx == (uint64_t)c->num_advice_columns - 1) c->row_offset += 1;   /* :229-231 */
     return assigned_spread_value;
 }
 
 /* spread.rs:76-123 SpreadConfig::spread */
-static ofe_t sc_spread(oracle_ctx *c, ofe_t dense) {
+static av_t sc_spread(oracle_ctx *c, av_t dense) {
     c->st.spread_calls++;
     int limb_bits = c->num_bits_lookup;                 /* :83 */
     int num_limbs = 16 / limb_bits;                     /* :84 */
-    ofe_t assigned_limbs[16];
+    av_t assigned_limbs[16];
     /* :85 decompose(v, num_limbs, limb_bits): little-endian limb_bits-wide digits */
     for (int idx = 0; idx < num_limbs; idx++) {
-        uint64_t limb = (dense.l[0] >> (limb_bits * idx)) & ((1ULL << limb_bits) - 1);
+        uint64_t limb = (dense.v.l[0] >> (limb_bits * idx)) & ((1ULL << limb_bits) - 1);
         assigned_limbs[idx] = g_load_witness(c, fe_u64(limb));          /* :86-88 */
     }
     {
-        ofe_t limbs_sum = g_load_zero(c);                               /* :90 */
+        av_t limbs_sum = g_load_zero(c);                                /* :90 */
         for (int idx = 0; idx < num_limbs; idx++)                       /* :91-98 */
-            limbs_sum = g_mul_add(c, assigned_limbs[idx], fe_u64(1ULL << (limb_bits * idx)), limbs_sum);
+            limbs_sum = g_mul_add(c, assigned_limbs[idx], K(1ULL << (limb_bits * idx)), limbs_sum);
         g_assert_equal(c, limbs_sum, dense);                            /* :104-108 */
     }
-    ofe_t assigned_spread = g_load_zero(c);                             /* :110 */
+    av_t assigned_spread = g_load_zero(c);                              /* :110 */
     for (int idx = 0; idx < num_limbs; idx++) {                         /* :112-121 */
-        ofe_t spread_limb = sc_spread_limb(c, assigned_limbs[idx]);
-        assigned_spread = g_mul_add(c, spread_limb, fe_u64(1ULL << (2 * limb_bits * idx)), assigned_spread);
+        av_t spread_limb = sc_spread_limb(c, assigned_limbs[idx]);
+        assigned_spread = g_mul_add(c, spread_limb, K(1ULL << (2 * limb_bits * idx)), assigned_spread);
     }
     return assigned_spread;
 }
 
 /* spread.rs:139-163 decompose_even_and_odd_unchecked */
-static void sc_decompose_even_and_odd_unchecked(oracle_ctx *c, ofe_t spread, ofe_t *even, ofe_t *odd) {
+static void sc_decompose_even_and_odd_unchecked(oracle_ctx *c, av_t spread, av_t *even, av_t *odd) {
     c->st.even_odd_calls++;
     uint8_t bits[32], eb[16], ob[16];
-    fe_to_bits_le(c, &spread, 32, bits);                /* :145 */
+    fe_to_bits_le(c, &spread.v, 32, bits);              /* :145 */
     for (int i = 0; i < 16; i++) { eb[i] = bits[2 * i]; ob[i] = bits[2 * i + 1]; }   /* :146-153 */
     ofe_t even_val = bits_le_to_fe(eb, 16), odd_val = bits_le_to_fe(ob, 16);         /* :154-157 */
     *even = g_load_witness(c, even_val);                /* :158 */
@@ -385,15 +462,15 @@ static const uint32_t ROUND_CONSTANTS[64] = {           /* FIPS 180-4 K; compres
 static const uint32_t INIT_STATE[8] = {                 /* compression.rs:1003-1012 */
     0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 
-typedef struct { ofe_t lo, hi; } spread_u32;            /* compression.rs:17 SpreadU32 */
+typedef struct { av_t lo, hi; } spread_u32;             /* compression.rs:17 SpreadU32 */
 
 /* compression.rs:215-246 */
-static spread_u32 state_to_spread_u32(oracle_ctx *c, ofe_t x) {
-    ofe_t lo = fe_u64(fe_lower_32(&x) & ((1u << 16) - 1));      /* :222-225 */
-    ofe_t hi = fe_u64(fe_lower_32(&x) >> 16);                   /* :226-229 */
-    ofe_t assigned_lo = g_load_witness(c, lo);                  /* :230 */
-    ofe_t assigned_hi = g_load_witness(c, hi);                  /* :231 */
-    ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 16), assigned_lo);   /* :232-237 */
+static spread_u32 state_to_spread_u32(oracle_ctx *c, av_t x) {
+    ofe_t lo = fe_u64(fe_lower_32(&x.v) & ((1u << 16) - 1));   /* :222-225 */
+    ofe_t hi = fe_u64(fe_lower_32(&x.v) >> 16);                /* :226-229 */
+    av_t assigned_lo = g_load_witness(c, lo);                   /* :230 */
+    av_t assigned_hi = g_load_witness(c, hi);                   /* :231 */
+    av_t composed = g_mul_add(c, assigned_hi, K(1ULL << 16), assigned_lo);   /* :232-237 */
     g_assert_equal(c, x, composed);                             /* :238-242 */
     spread_u32 r;
     r.lo = sc_spread(c, assigned_lo);                           /* :243 */
@@ -402,42 +479,42 @@ static spread_u32 state_to_spread_u32(oracle_ctx *c, ofe_t x) {
 }
 
 /* compression.rs:266-295 */
-static ofe_t mod_u32(oracle_ctx *c, ofe_t x) {
-    ofe_t lo = fe_u64(fe_lower_32(&x));                                     /* :272-275 */
-    ofe_t hi = fe_u64((fe_lower_64(&x) >> 32) & ((1ULL << 32) - 1));        /* :276-279 */
-    ofe_t assigned_lo = g_load_witness(c, lo);                              /* :280 */
-    ofe_t assigned_hi = g_load_witness(c, hi);                              /* :281 */
+static av_t mod_u32(oracle_ctx *c, av_t x) {
+    ofe_t lo = fe_u64(fe_lower_32(&x.v));                                   /* :272-275 */
+    ofe_t hi = fe_u64((fe_lower_64(&x.v) >> 32) & ((1ULL << 32) - 1));      /* :276-279 */
+    av_t assigned_lo = g_load_witness(c, lo);                               /* :280 */
+    av_t assigned_hi = g_load_witness(c, hi);                               /* :281 */
     r_range_check(c, assigned_lo, 32);                                      /* :282 */
-    ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 32), assigned_lo);   /* :283-288 */
+    av_t composed = g_mul_add(c, assigned_hi, K(1ULL << 32), assigned_lo);  /* :283-288 */
     g_assert_equal(c, x, composed);                                         /* :289-293 */
     return assigned_lo;
 }
 
 /* compression.rs:521-530 */
-static ofe_t three_add(oracle_ctx *c, ofe_t x, ofe_t y, ofe_t z) {
-    ofe_t add1 = g_add(c, x, y);
+static av_t three_add(oracle_ctx *c, av_t x, av_t y, av_t z) {
+    av_t add1 = g_add(c, x, y);
     return g_add(c, add1, z);
 }
 
 /* the { spread(even); spread(odd); 2*odd+even == whole } block that ch, maj
  * and sigma_generic each repeat (compression.rs:344-354 and siblings) */
-static void recheck_even_odd(oracle_ctx *c, ofe_t even, ofe_t odd, ofe_t whole) {
-    ofe_t even_spread = sc_spread(c, even);
-    ofe_t odd_spread = sc_spread(c, odd);
-    ofe_t sum = g_mul_add(c, fe_u64(2), odd_spread, even_spread);
+static void recheck_even_odd(oracle_ctx *c, av_t even, av_t odd, av_t whole) {
+    av_t even_spread = sc_spread(c, even);
+    av_t odd_spread = sc_spread(c, odd);
+    av_t sum = g_mul_add(c, K(2), odd_spread, even_spread);
     g_assert_equal(c, sum, whole);
 }
 
 /* compression.rs:297-405 */
-static ofe_t ch(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
-    ofe_t p_lo = g_add(c, x.lo, y.lo);                          /* :309-313 */
-    ofe_t p_hi = g_add(c, x.hi, y.hi);                          /* :314-318 */
+static av_t ch(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
+    av_t p_lo = g_add(c, x.lo, y.lo);                           /* :309-313 */
+    av_t p_hi = g_add(c, x.hi, y.hi);                           /* :314-318 */
     const uint64_t MASK_EVEN_32 = 0x55555555;                   /* :319 */
-    ofe_t x_neg_lo = g_neg(c, x.lo);                            /* :320 */
-    ofe_t x_neg_hi = g_neg(c, x.hi);                            /* :321 */
-    ofe_t q_lo = three_add(c, fe_u64(MASK_EVEN_32), x_neg_lo, z.lo);    /* :322-328 */
-    ofe_t q_hi = three_add(c, fe_u64(MASK_EVEN_32), x_neg_hi, z.hi);    /* :329-335 */
-    ofe_t p_lo_even, p_lo_odd, p_hi_even, p_hi_odd, q_lo_even, q_lo_odd, q_hi_even, q_hi_odd;
+    av_t x_neg_lo = g_neg(c, x.lo);                             /* :320 */
+    av_t x_neg_hi = g_neg(c, x.hi);                             /* :321 */
+    av_t q_lo = three_add(c, K(MASK_EVEN_32), x_neg_lo, z.lo);  /* :322-328 */
+    av_t q_hi = three_add(c, K(MASK_EVEN_32), x_neg_hi, z.hi);  /* :329-335 */
+    av_t p_lo_even, p_lo_odd, p_hi_even, p_hi_odd, q_lo_even, q_lo_odd, q_hi_even, q_hi_odd;
     sc_decompose_even_and_odd_unchecked(c, p_lo, &p_lo_even, &p_lo_odd);    /* :336-337 */
     sc_decompose_even_and_odd_unchecked(c, p_hi, &p_hi_even, &p_hi_odd);    /* :338-339 */
     sc_decompose_even_and_odd_unchecked(c, q_lo, &q_lo_even, &q_lo_odd);    /* :340-341 */
@@ -446,32 +523,32 @@ static ofe_t ch(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
     recheck_even_odd(c, p_hi_even, p_hi_odd, p_hi);             /* :355-365 */
     recheck_even_odd(c, q_lo_even, q_lo_odd, q_lo);             /* :366-376 */
     recheck_even_odd(c, q_hi_even, q_hi_odd, q_hi);             /* :377-387 */
-    ofe_t out_lo = g_add(c, p_lo_odd, q_lo_odd);                /* :388-392 */
-    ofe_t out_hi = g_add(c, p_hi_odd, q_hi_odd);                /* :393-397 */
-    return g_mul_add(c, out_hi, fe_u64(1ULL << 16), out_lo);    /* :398-403 */
+    av_t out_lo = g_add(c, p_lo_odd, q_lo_odd);                 /* :388-392 */
+    av_t out_hi = g_add(c, p_hi_odd, q_hi_odd);                 /* :393-397 */
+    return g_mul_add(c, out_hi, K(1ULL << 16), out_lo);         /* :398-403 */
 }
 
 /* compression.rs:460-519 */
-static ofe_t maj(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
-    ofe_t m_lo = three_add(c, x.lo, y.lo, z.lo);                /* :472-478 */
-    ofe_t m_hi = three_add(c, x.hi, y.hi, z.hi);                /* :479-485 */
-    ofe_t m_lo_even, m_lo_odd, m_hi_even, m_hi_odd;
+static av_t maj(oracle_ctx *c, spread_u32 x, spread_u32 y, spread_u32 z) {
+    av_t m_lo = three_add(c, x.lo, y.lo, z.lo);                 /* :472-478 */
+    av_t m_hi = three_add(c, x.hi, y.hi, z.hi);                 /* :479-485 */
+    av_t m_lo_even, m_lo_odd, m_hi_even, m_hi_odd;
     sc_decompose_even_and_odd_unchecked(c, m_lo, &m_lo_even, &m_lo_odd);    /* :486-487 */
     sc_decompose_even_and_odd_unchecked(c, m_hi, &m_hi_even, &m_hi_odd);    /* :488-489 */
     recheck_even_odd(c, m_lo_even, m_lo_odd, m_lo);             /* :490-500 */
     recheck_even_odd(c, m_hi_even, m_hi_odd, m_hi);             /* :501-511 */
-    return g_mul_add(c, m_hi_odd, fe_u64(1ULL << 16), m_lo_odd);        /* :512-517 */
+    return g_mul_add(c, m_hi_odd, K(1ULL << 16), m_lo_odd);     /* :512-517 */
 }
 
 /* compression.rs:702-882 */
 typedef struct { int starts[4], ends[4]; uint64_t coeffs[4]; } sigma_params;
-static ofe_t sigma_generic(oracle_ctx *c, const spread_u32 *x_spread, const sigma_params *sp) {
+static av_t sigma_generic(oracle_ctx *c, const spread_u32 *x_spread, const sigma_params *sp) {
     const int *starts = sp->starts, *ends = sp->ends;
     const uint64_t *coeffs = sp->coeffs;
     uint8_t bits[64];
-    fe_to_bits_le(c, &x_spread->lo, 32, bits);                  /* :715 */
-    fe_to_bits_le(c, &x_spread->hi, 32, bits + 32);             /* :716 */
-    ofe_t assigned[4];
+    fe_to_bits_le(c, &x_spread->lo.v, 32, bits);                /* :715 */
+    fe_to_bits_le(c, &x_spread->hi.v, 32, bits + 32);           /* :716 */
+    av_t assigned[4];
     for (int i = 0; i < 4; i++) {                               /* :719-734 assign_bits x4 */
         uint8_t piece[64];
         int n = 2 * ends[i] - 2 * starts[i];
@@ -480,105 +557,106 @@ static ofe_t sigma_generic(oracle_ctx *c, const spread_u32 *x_spread, const sigm
         assigned[i] = g_load_witness(c, bits_le_to_fe(piece, 64));      /* :724-726 */
     }
     {
-        ofe_t sum = assigned[0];                                /* :736 */
-        sum = g_mul_add(c, assigned[1], fe_u64(1ULL << (2 * starts[1])), sum);     /* :737-742 */
-        sum = g_mul_add(c, assigned[2], fe_u64(1ULL << (2 * starts[2])), sum);     /* :743-748 */
-        sum = g_mul_add(c, assigned[3], fe_u64(1ULL << (2 * starts[3])), sum);     /* :749-754 */
-        ofe_t x_composed = g_mul_add(c, x_spread->hi, fe_u64(1ULL << 32), x_spread->lo);   /* :755-760 */
+        av_t sum = assigned[0];                                 /* :736 */
+        sum = g_mul_add(c, assigned[1], K(1ULL << (2 * starts[1])), sum);     /* :737-742 */
+        sum = g_mul_add(c, assigned[2], K(1ULL << (2 * starts[2])), sum);     /* :743-748 */
+        sum = g_mul_add(c, assigned[3], K(1ULL << (2 * starts[3])), sum);     /* :749-754 */
+        av_t x_composed = g_mul_add(c, x_spread->hi, K(1ULL << 32), x_spread->lo);   /* :755-760 */
         g_assert_equal(c, x_composed, sum);                     /* :761-765 */
     }
-    ofe_t r_spread;
+    av_t r_spread;
     {
-        ofe_t sum = g_load_zero(c);                             /* :780 */
+        av_t sum = g_load_zero(c);                              /* :780 */
         for (int i = 0; i < 4; i++)                             /* :785-808 */
-            sum = g_mul_add(c, fe_u64(coeffs[i]), assigned[i], sum);
+            sum = g_mul_add(c, K(coeffs[i]), assigned[i], sum);
         r_spread = sum;
     }
-    ofe_t r_lo, r_hi;
+    av_t r_lo, r_hi;
     {
-        ofe_t lo = fe_u64(fe_lower_32(&r_spread));                              /* :812-815 */
-        ofe_t hi = fe_u64((fe_lower_64(&r_spread) >> 32) & ((1ULL << 32) - 1)); /* :816-819 */
-        ofe_t assigned_lo = g_load_witness(c, lo);              /* :820 */
-        ofe_t assigned_hi = g_load_witness(c, hi);              /* :821 */
+        ofe_t lo = fe_u64(fe_lower_32(&r_spread.v));                              /* :812-815 */
+        ofe_t hi = fe_u64((fe_lower_64(&r_spread.v) >> 32) & ((1ULL << 32) - 1)); /* :816-819 */
+        av_t assigned_lo = g_load_witness(c, lo);               /* :820 */
+        av_t assigned_hi = g_load_witness(c, hi);               /* :821 */
         r_range_check(c, assigned_lo, 32);                      /* :822 */
         r_range_check(c, assigned_hi, 32);                      /* :823 */
-        ofe_t composed = g_mul_add(c, assigned_hi, fe_u64(1ULL << 32), assigned_lo);   /* :824-829 */
+        av_t composed = g_mul_add(c, assigned_hi, K(1ULL << 32), assigned_lo);   /* :824-829 */
         g_assert_equal(c, r_spread, composed);                  /* :830-834 */
         r_lo = assigned_lo; r_hi = assigned_hi;
     }
-    ofe_t r_lo_even, r_lo_odd, r_hi_even, r_hi_odd;
+    av_t r_lo_even, r_lo_odd, r_hi_even, r_hi_odd;
     sc_decompose_even_and_odd_unchecked(c, r_lo, &r_lo_even, &r_lo_odd);    /* :843-844 */
     sc_decompose_even_and_odd_unchecked(c, r_hi, &r_hi_even, &r_hi_odd);    /* :845-846 */
     recheck_even_odd(c, r_lo_even, r_lo_odd, r_lo);             /* :852-862 */
     recheck_even_odd(c, r_hi_even, r_hi_odd, r_hi);             /* :863-873 */
-    return g_mul_add(c, r_hi_even, fe_u64(1ULL << 16), r_lo_even);      /* :874-879 */
+    return g_mul_add(c, r_hi_even, K(1ULL << 16), r_lo_even);   /* :874-879 */
 }
 
 #define P2(n) (1ULL << (n))
 /* compression.rs:594-619 */
-static ofe_t sigma_upper0(oracle_ctx *c, const spread_u32 *x) {
+static av_t sigma_upper0(oracle_ctx *c, const spread_u32 *x) {
     static const sigma_params SP = {{0, 2, 13, 22}, {2, 13, 22, 32},
                                     {P2(60) + P2(38) + P2(20), P2(0) + P2(42) + P2(24),
-                                       P2(22) + P2(0) + P2(46), P2(40) + P2(18) + P2(0)}};
+                                     P2(22) + P2(0) + P2(46), P2(40) + P2(18) + P2(0)}};
     return sigma_generic(c, x, &SP);
 }
 /* compression.rs:621-646 */
-static ofe_t sigma_upper1(oracle_ctx *c, const spread_u32 *x) {
+static av_t sigma_upper1(oracle_ctx *c, const spread_u32 *x) {
     static const sigma_params SP = {{0, 6, 11, 25}, {6, 11, 25, 32},
                                     {P2(52) + P2(42) + P2(14), P2(0) + P2(54) + P2(26),
-                                       P2(10) + P2(0) + P2(36), P2(38) + P2(28) + P2(0)}};
+                                     P2(10) + P2(0) + P2(36), P2(38) + P2(28) + P2(0)}};
     return sigma_generic(c, x, &SP);
 }
 /* compression.rs:648-673 */
-static ofe_t sigma_lower0(oracle_ctx *c, const spread_u32 *x) {
+static av_t sigma_lower0(oracle_ctx *c, const spread_u32 *x) {
     static const sigma_params SP = {{0, 3, 7, 18}, {3, 7, 18, 32},
                                     {P2(50) + P2(28), P2(0) + P2(56) + P2(34),
-                                       P2(8) + P2(0) + P2(42), P2(30) + P2(22) + P2(0)}};
+                                     P2(8) + P2(0) + P2(42), P2(30) + P2(22) + P2(0)}};
     return sigma_generic(c, x, &SP);
 }
 /* compression.rs:675-700 */
-static ofe_t sigma_lower1(oracle_ctx *c, const spread_u32 *x) {
+static av_t sigma_lower1(oracle_ctx *c, const spread_u32 *x) {
     static const sigma_params SP = {{0, 10, 17, 19}, {10, 17, 19, 32},
                                     {P2(30) + P2(26), P2(0) + P2(50) + P2(46),
-                                       P2(14) + P2(0) + P2(60), P2(18) + P2(4) + P2(0)}};
+                                     P2(14) + P2(0) + P2(60), P2(18) + P2(4) + P2(0)}};
     return sigma_generic(c, x, &SP);
 }
 
 /* compression.rs:19-213 */
 int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
                               const uint32_t pre_state[8], uint32_t next_state[8]) {
-    /* the caller's assigned_input_bytes / pre_state_words (lib.rs:162-173) */
-    ofe_t assigned_input_bytes[64], pre_state_words[8];
-    for (int i = 0; i < 64; i++) assigned_input_bytes[i] = fe_u64(block[i]);
-    for (int i = 0; i < 8; i++) pre_state_words[i] = fe_u64(pre_state[i]);
+    c->block_start = c->gate_len;
+    /* the caller's assigned_input_bytes / pre_state_words (lib.rs:162-173): cells outside the stream */
+    av_t assigned_input_bytes[64], pre_state_words[8];
+    for (int i = 0; i < 64; i++) assigned_input_bytes[i] = ext_cell(block[i], ORACLE_CELL_INPUT_BYTE0 - i);
+    for (int i = 0; i < 8; i++) pre_state_words[i] = ext_cell(pre_state[i], ORACLE_CELL_PRE_STATE0 - i);
 
     /* message schedule: :31-47 */
-    ofe_t message_u32s[64];
+    av_t message_u32s[64];
     for (int w = 0; w < 16; w++) {
-        const ofe_t *bytes = &assigned_input_bytes[4 * w];
-        ofe_t sum = g_load_zero(c);                                         /* :34 */
+        const av_t *bytes = &assigned_input_bytes[4 * w];
+        av_t sum = g_load_zero(c);                                          /* :34 */
         for (int idx = 0; idx < 4; idx++)                                   /* :35-42 */
-            sum = g_mul_add(c, bytes[3 - idx], fe_u64(1ULL << (8 * idx)), sum);
+            sum = g_mul_add(c, bytes[3 - idx], K(1ULL << (8 * idx)), sum);
         message_u32s[w] = sum;
     }
     spread_u32 message_spreads[64];
     for (int w = 0; w < 16; w++)                                            /* :53-56 */
         message_spreads[w] = state_to_spread_u32(c, message_u32s[w]);
     for (int idx = 16; idx < 64; idx++) {                                   /* :57-96 */
-        ofe_t term1 = sigma_lower1(c, &message_spreads[idx - 2]);           /* :60 */
-        ofe_t term3 = sigma_lower0(c, &message_spreads[idx - 15]);          /* :61 */
-        ofe_t sum = g_add(c, term1, message_u32s[idx - 7]);                 /* :65-69 */
+        av_t term1 = sigma_lower1(c, &message_spreads[idx - 2]);            /* :60 */
+        av_t term3 = sigma_lower0(c, &message_spreads[idx - 15]);           /* :61 */
+        av_t sum = g_add(c, term1, message_u32s[idx - 7]);                  /* :65-69 */
         sum = g_add(c, sum, term3);                                         /* :70-74 */
         sum = g_add(c, sum, message_u32s[idx - 16]);                        /* :75-79 */
-        ofe_t new_w = mod_u32(c, sum);                                      /* :80 */
+        av_t new_w = mod_u32(c, sum);                                       /* :80 */
         message_u32s[idx] = new_w;                                          /* :89 */
         message_spreads[idx] = state_to_spread_u32(c, new_w);               /* :90-91 */
     }
 
     /* compression: :99-124 */
-    ofe_t a = pre_state_words[0], b = pre_state_words[1], cc = pre_state_words[2],
-          d = pre_state_words[3], e = pre_state_words[4], f = pre_state_words[5],
-          g = pre_state_words[6], h = pre_state_words[7];
+    av_t a = pre_state_words[0], b = pre_state_words[1], cc = pre_state_words[2],
+         d = pre_state_words[3], e = pre_state_words[4], f = pre_state_words[5],
+         g = pre_state_words[6], h = pre_state_words[7];
     spread_u32 a_spread = state_to_spread_u32(c, a);        /* :109 */
     spread_u32 b_spread = state_to_spread_u32(c, b);        /* :110 */
     spread_u32 c_spread = state_to_spread_u32(c, cc);       /* :111 */
@@ -588,27 +666,27 @@ int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
     g_load_zero(c);                                         /* :123 */
     g_load_zero(c);                                         /* :124 */
     for (int idx = 0; idx < 64; idx++) {                    /* :125-196 */
-        ofe_t t1, t2;
+        av_t t1, t2;
         {
-            ofe_t sigma_term = sigma_upper1(c, &e_spread);                  /* :130 */
-            ofe_t ch_term = ch(c, e_spread, f_spread, g_spread);            /* :131 */
-            ofe_t add1 = g_add(c, h, sigma_term);                           /* :138-142 */
-            ofe_t add2 = g_add(c, add1, ch_term);                           /* :143-147 */
-            ofe_t add3 = g_add(c, add2, fe_u64(ROUND_CONSTANTS[idx]));      /* :148-152 */
-            ofe_t add4 = g_add(c, add3, message_u32s[idx]);                 /* :153-157 */
+            av_t sigma_term = sigma_upper1(c, &e_spread);                   /* :130 */
+            av_t ch_term = ch(c, e_spread, f_spread, g_spread);             /* :131 */
+            av_t add1 = g_add(c, h, sigma_term);                            /* :138-142 */
+            av_t add2 = g_add(c, add1, ch_term);                            /* :143-147 */
+            av_t add3 = g_add(c, add2, K(ROUND_CONSTANTS[idx]));            /* :148-152 */
+            av_t add4 = g_add(c, add3, message_u32s[idx]);                  /* :153-157 */
             t1 = mod_u32(c, add4);                                          /* :158 */
         }
         {
-            ofe_t sigma_term = sigma_upper0(c, &a_spread);                  /* :164 */
-            ofe_t maj_term = maj(c, a_spread, b_spread, c_spread);          /* :165 */
-            ofe_t add = g_add(c, sigma_term, maj_term);                     /* :166-170 */
+            av_t sigma_term = sigma_upper0(c, &a_spread);                   /* :164 */
+            av_t maj_term = maj(c, a_spread, b_spread, c_spread);           /* :165 */
+            av_t add = g_add(c, sigma_term, maj_term);                      /* :166-170 */
             t2 = mod_u32(c, add);                                           /* :171 */
         }
         h = g;                                              /* :174 */
         g = f; g_spread = f_spread;                         /* :176-177 */
         f = e; f_spread = e_spread;                         /* :178-179 */
         {
-            ofe_t add = g_add(c, d, t1);                    /* :181 */
+            av_t add = g_add(c, d, t1);                     /* :181 */
             e = mod_u32(c, add);                            /* :182 */
         }
         e_spread = state_to_spread_u32(c, e);               /* :184 */
@@ -616,17 +694,19 @@ int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
         cc = b; c_spread = b_spread;                        /* :187-188 */
         b = a; b_spread = a_spread;                         /* :189-190 */
         {
-            ofe_t add = g_add(c, t1, t2);                   /* :192 */
+            av_t add = g_add(c, t1, t2);                    /* :192 */
             a = mod_u32(c, add);                            /* :193 */
         }
         a_spread = state_to_spread_u32(c, a);               /* :195 */
     }
-    ofe_t new_states[8] = {a, b, cc, d, e, f, g, h};        /* :197 */
+    av_t new_states[8] = {a, b, cc, d, e, f, g, h};         /* :197 */
     for (int i = 0; i < 8; i++) {                           /* :198-211 */
-        ofe_t add = g_add(c, new_states[i], pre_state_words[i]);
-        ofe_t out = mod_u32(c, add);
-        if (next_state) next_state[i] = fe_lower_32(&out);
+        av_t add = g_add(c, new_states[i], pre_state_words[i]);
+        av_t out = mod_u32(c, add);
+        if (next_state) next_state[i] = fe_lower_32(&out.v);
+        if (c->rec && c->rec->next_state_cells) c->rec->next_state_cells[i] = out.cell;
     }
+    c->rec = NULL;      /* the structure is input independent: recorded for one block only */
     return c->failed;
 }
 

@@ -71,6 +71,32 @@ typedef struct {
 
 typedef struct oracle_ctx oracle_ctx;
 
+/* The constraint STRUCTURE of one block, as the reference's source specifies it
+ * (QuantumCell::Existing / Constant / Witness per gate input, assert_equal,
+ * range_check, spread_limb's constrain_equal): independent of any input, and of
+ * any value the oracle computes.  Together with the gate rows of the tape
+ * (x0 + x1*x2 = x3) and the two lookup tables this is everything
+ * MockProver::verify checks for the path (lib.rs:525-526), so a stream that
+ * satisfies it is THE witness for its inputs (uniqueness).
+ * Cell ids: >= 0 = block-relative index in the gate stream; negative = cells
+ * outside it (below).  Arrays may be NULL to only count. */
+#define ORACLE_CELL_ZERO        (-1000)        /* the cached load_zero cell (value 0)        */
+#define ORACLE_CELL_INPUT_BYTE0 (-1)           /* input byte k lives in cell -1 - k          */
+#define ORACLE_CELL_PRE_STATE0  (-100)         /* pre-state word i lives in cell -100 - i    */
+#define ORACLE_CELL_HIDDEN      (-2000)        /* a halo2-base witness that is not in the stream
+                                                  (range-check limbs without internals)     */
+typedef struct {
+    int64_t *eq;     size_t eq_cap, n_eq;         /* pairs (a, b): cells copy-constrained equal          */
+    int64_t *konst;  size_t const_cap, n_const;   /* pairs (cell, k): cell fixed to the constant k < 2^64 */
+    int64_t *range;  size_t range_cap, n_range;   /* pairs (cell, bits): cell < 2^bits                    */
+    int64_t *chip;   size_t chip_cap, n_chip;     /* limb call n: (cell equal to chip dense cell n,
+                                                     cell equal to chip spread cell n)                  */
+    int64_t *lookup_src; size_t lookup_cap, n_lookup;   /* lookup-column entry j copies this cell        */
+    int64_t *next_state_cells;                    /* 8 cells holding the next state words, or NULL        */
+} oracle_constraints_t;
+/* Record the structure while the NEXT block is expanded (then detaches itself). */
+void oracle_record_constraints(oracle_ctx *c, oracle_constraints_t *rec);
+
 /* Create a context for SpreadConfig::configure(num_bits_lookup,
  * num_advice_columns) (spread.rs:32-74).  check!=0 turns on every
  * assert_equal / range / lookup self-check.  Returns NULL on bad shape. */

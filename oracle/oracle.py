@@ -54,6 +54,7 @@ def lib():
                                          C.c_void_p, C.c_size_t, C.c_uint64]
         L.oracle_set_cursor.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_set_kinds.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_record_constraints.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_set_internals.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_lookup_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_lookup_len.restype = C.c_size_t
@@ -219,6 +220,61 @@ class Oracle:
         out.update(digest=dig.tobytes(), blocks=blocks[:nblk], pre_states=pre[:nblk],
                    next_states=nxt[:nblk])
         return out
+
+
+CELL_ZERO = -1000
+CELL_INPUT_BYTE0 = -1
+CELL_PRE_STATE0 = -100
+CELL_HIDDEN = -2000
+
+
+class _Constraints(C.Structure):
+    _fields_ = [("eq", C.c_void_p), ("eq_cap", C.c_size_t), ("n_eq", C.c_size_t),
+                ("konst", C.c_void_p), ("const_cap", C.c_size_t), ("n_const", C.c_size_t),
+                ("range", C.c_void_p), ("range_cap", C.c_size_t), ("n_range", C.c_size_t),
+                ("chip", C.c_void_p), ("chip_cap", C.c_size_t), ("n_chip", C.c_size_t),
+                ("lookup_src", C.c_void_p), ("lookup_cap", C.c_size_t), ("n_lookup", C.c_size_t),
+                ("next_state_cells", C.c_void_p)]
+
+
+_cs_cache = {}
+
+
+def constraint_system(num_bits_lookup=8, num_advice_columns=2, internals=False):
+    """The constraint STRUCTURE of one block as the reference's source specifies it
+    (hsw_oracle.h oracle_constraints_t): dict of int64 numpy arrays
+      eq (n,2), const (n,2), range (n,2), chip (limb calls,2), lookup_src (n,), next_state_cells (8,)
+    plus gate_starts (first cell of every 4-cell gate row).  Input independent."""
+    key = (num_bits_lookup, num_advice_columns, bool(internals))
+    if key in _cs_cache:
+        return _cs_cache[key]
+    G, LC = measure_shape(num_bits_lookup, num_advice_columns, internals)
+    LK = lookup_cells_per_block(num_bits_lookup, num_advice_columns)
+    o = Oracle(num_bits_lookup, num_advice_columns, check=True, internals=internals)
+    cap = 4 * G
+    eq = np.zeros((cap, 2), dtype=np.int64)
+    konst = np.zeros((cap, 2), dtype=np.int64)
+    rng_ = np.zeros((cap, 2), dtype=np.int64)
+    chip = np.zeros((LC, 2), dtype=np.int64)
+    lk = np.zeros(LK, dtype=np.int64)
+    nsc = np.zeros(8, dtype=np.int64)
+    cs = _Constraints(eq.ctypes.data, cap, 0, konst.ctypes.data, cap, 0, rng_.ctypes.data, cap, 0,
+                      chip.ctypes.data, LC, 0, lk.ctypes.data, LK, 0, nsc.ctypes.data)
+    kinds = np.zeros(G, dtype=np.uint8)
+    o.L.oracle_set_outputs(o.h, None, 0, None, None, 0, 0)
+    o.L.oracle_set_kinds(o.h, kinds.ctypes.data, G)
+    o.L.oracle_record_constraints(o.h, C.byref(cs))
+    blk = (np.arange(64, dtype=np.uint8) * 13 + 5).astype(np.uint8)
+    nxt = np.zeros(8, dtype=np.uint32)
+    o.L.oracle_sha256_compression(o.h, blk.ctypes.data, INIT_STATE.ctypes.data, nxt.ctypes.data)
+    o.L.oracle_set_kinds(o.h, None, 0)
+    o._check()
+    assert cs.n_eq <= cap and cs.n_const <= cap and cs.n_range <= cap and cs.n_chip == LC and cs.n_lookup == LK
+    res = dict(eq=eq[:cs.n_eq].copy(), const=konst[:cs.n_const].copy(), range=rng_[:cs.n_range].copy(),
+               chip=chip.copy(), lookup_src=lk.copy(), next_state_cells=nsc.copy(),
+               gate_starts=np.nonzero(kinds == 1)[0].astype(np.int64), kinds=kinds, G=G, LC=LC, LK=LK)
+    _cs_cache[key] = res
+    return res
 
 
 def gate_tape(num_bits_lookup=8, num_advice_columns=2, internals=False):

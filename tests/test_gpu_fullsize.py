@@ -106,3 +106,67 @@ def test_full_batch_properties(engine_factory, oracle):
     eng.synchronize()
     assert h1 == [int(out2["gate"].sum()), int(out2["dense"].sum()), int(out2["spread"].sum())]
     assert bool((out2["gate"][:G] == first).all())
+
+
+def _check_on_gpu(oracle, eng, blocks, pre, out, internals, chunk=256):
+    """MockProver-style verification of the GPU streams against the reference's
+    constraint STRUCTURE (tests/constraint_check.py): no oracle-computed value is used."""
+    import torch
+    from tests.constraint_check import check_block_batch, chip_in_call_order
+    n = blocks.shape[0]
+    cs = oracle.constraint_system(8, 2, internals)
+    G, LC, LK = cs["G"], cs["LC"], cs["LK"]
+    assert eng.G == G
+    gate = out["gate"].view(n, G, 4)
+    dl = chip_in_call_order(torch, out["dense"], n, LC, 2)
+    sl = chip_in_call_order(torch, out["spread"], n, LC, 2)
+    tab = [s for _, s in oracle.spread_table(8)]
+    tb = torch.from_numpy(blocks.astype(np.int64)).cuda()
+    tp = torch.from_numpy(pre.astype(np.int64)).cuda()
+    ns = out["next_states"].to(torch.int64) & 0xFFFFFFFF
+    lk = out["lookup"][:, 0].view(n, LK) if internals else None
+    total = 0
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        total += check_block_batch(torch, cs, gate[lo:hi], tb[lo:hi], tp[lo:hi], dl[lo:hi], sl[lo:hi], ns[lo:hi],
+                                   lk[lo:hi] if internals else None, tab, 8)
+    return total
+
+
+def test_full_batch_satisfies_the_reference_constraint_system(engine_factory, oracle):
+    """All 4,096 blocks of BASELINE configs[2]: every gate row, every copy constraint
+    (assert_equal + Existing gate inputs), every fixed constant, every range bound, every
+    chip-cell tie and spread lookup, and the digest -- what MockProver::verify checks
+    (lib.rs:525-526) -- evaluated on the GPU output without any oracle value."""
+    import torch
+    eng = engine_factory(8, 2)
+    msgs, blocks = _workload()
+    pre = np.tile(oracle.INIT_STATE, (N_MSG, 1))
+    out = eng.witness_blocks(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda())
+    eng.synchronize()
+    total = _check_on_gpu(oracle, eng, blocks, pre, out, internals=False)
+    assert total > N_MSG * 70000
+    # inputs are tied through the external cells: a stream computed for OTHER inputs must fail
+    other = blocks.copy()
+    other[5, 7] ^= 0x10
+    with pytest.raises(AssertionError):
+        _check_on_gpu(oracle, eng, other[:256], pre[:256], {k: (v[:256 * eng.G] if k == "gate" else
+                      (v[:, :256 * 2060] if k in ("dense", "spread") else v[:256])) for k, v in out.items()
+                      if k in ("gate", "dense", "spread", "next_states")}, internals=False)
+
+
+def test_internals_mode_satisfies_constraints_including_lookup_column(hsw, oracle):
+    """HSW_MODE_HALO2_INTERNALS on 512 blocks: the range_check rows are real gate rows now, their
+    limbs are tied to the lookup column, and constrain_equal(a, acc) is a recorded copy constraint."""
+    import torch
+    eng = hsw.WitnessEngine(0, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    n = 512
+    rng = np.random.default_rng(0xC3)
+    blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    out = eng.witness_blocks_ex(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                                want_lookup=True)
+    eng.synchronize()
+    total = _check_on_gpu(oracle, eng, blocks, pre, out, internals=True)
+    assert total > n * 75000
+    eng.close()
