@@ -168,12 +168,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # Rehearsal knobs (not used by the driver): HSW_BENCH_BACKEND=gloo and HSW_BENCH_SAME_DEVICE=1 run
+    # the multi-rank control flow on a box with ONE GPU (all ranks on cuda:0, collectives on the CPU).
+    backend = os.environ.get("HSW_BENCH_BACKEND", "nccl")
+    if os.environ.get("HSW_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     hsw = importlib.import_module("halo2-dynamic-sha256_amd")
     eng = hsw.WitnessEngine(local_rank, 8, 2)
@@ -239,7 +248,7 @@ def main():
         dig = b"".join(int(x).to_bytes(4, "big") for x in ns[i])
         assert dig == hashlib.sha256(msgs[i].tobytes()).digest(), "GPU digest mismatch"
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if distributed:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
