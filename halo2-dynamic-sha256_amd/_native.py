@@ -25,6 +25,7 @@ HSW_REPR_MONTGOMERY = 1
 HSW_SKIP_GATE = 2
 HSW_SKIP_CHIP = 4
 HSW_HOST_REGISTER = 8
+HSW_REPR_COMPACT64 = 16
 HSW_MODE_DEFAULT = 0
 HSW_MODE_HALO2_INTERNALS = 1
 HSW_MAX_BREAKS = 8
@@ -86,7 +87,7 @@ SYMBOLS = (
     "hsw_gadget_digest", "hsw_gadget_digest_batch", "hsw_gadget_streams", "hsw_gadget_input_bytes",
     "hsw_gadget_set_repr", "hsw_download", "hsw_host_alloc", "hsw_host_free",
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
-    "hsw_witness_blocks_ex", "hsw_spread_table",
+    "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
 )
 
 
@@ -176,6 +177,10 @@ def lib():
         L.hsw_gate_tape.argtypes = [C.POINTER(Shape), vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.hsw_witness_blocks_ex.restype = C.c_int
         L.hsw_witness_blocks_ex.argtypes = [vp, C.POINTER(WitnessArgs)]
+        L.hsw_cell_bytes.restype = C.c_uint32
+        L.hsw_cell_bytes.argtypes = [C.c_uint32]
+        L.hsw_neg_cells.restype = C.c_int
+        L.hsw_neg_cells.argtypes = [C.POINTER(Shape), vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.hsw_spread_table.restype = C.c_int
         L.hsw_spread_table.argtypes = [C.c_uint32, vp, vp]
         L.hsw_host_alloc.restype = C.c_int
@@ -229,6 +234,17 @@ def spread_table(num_bits_lookup=8):
     if rc != HSW_OK:
         raise HswError(rc)
     return d, s
+
+
+def neg_cells(shape):
+    """Block-relative gate cells holding field negations (hsw_neg_cells), numpy uint32."""
+    import numpy as np
+    out = np.zeros(256, dtype=np.uint32)
+    n = C.c_size_t()
+    rc = lib().hsw_neg_cells(C.byref(shape), out.ctypes.data, 256, C.byref(n))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return out[: n.value]
 
 
 def gate_tape(shape):

@@ -173,6 +173,22 @@ int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *sp
     return HSW_OK;
 }
 
+uint32_t hsw_cell_bytes(uint32_t flags) { return (flags & HSW_REPR_COMPACT64) ? 8u : HSW_CELL_BYTES; }
+
+int hsw_neg_cells(const hsw_shape *s, uint32_t *out, size_t cap, size_t *n) {
+    if (!s || s->cells_per_round == 0) return HSW_ERR_INVALID_ARG;
+    if (n) *n = 256;
+    if (out) {
+        if (cap < 256) return HSW_ERR_INVALID_ARG;
+        // inside ch: 2 add rows (8 cells), neg rows [a,-a,1,0] x2, then add(M,-x) / add(.,z) twice
+        static const uint32_t in_ch[4] = {9, 13, 17, 25};
+        for (uint32_t r = 0; r < 64; r++)
+            for (int k = 0; k < 4; k++)
+                out[4 * r + k] = s->off_rounds + r * s->cells_per_round + s->cells_per_sigma + in_ch[k];
+    }
+    return HSW_OK;
+}
+
 uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) {
     if (!s || s->num_advice_columns == 0 || s->limb_calls_per_block == 0) return 0;
     const uint64_t nc = s->num_advice_columns;
@@ -316,6 +332,9 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
     if (n_blocks == 0) return HSW_OK;
     if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP))
         return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
+    if ((flags & HSW_REPR_MASK) == HSW_REPR_MASK)
+        return set_err(e, HSW_ERR_INVALID_ARG, "HSW_REPR_MONTGOMERY and HSW_REPR_COMPACT64 are exclusive");
+    const size_t cb = hsw_cell_bytes(flags);
     if (!d_blocks || !d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
     if (((uintptr_t)d_blocks & 3u) || ((uintptr_t)d_pre_states & 3u))
         return set_err(e, HSW_ERR_INVALID_ARG, "inputs must be 4-byte aligned");
@@ -352,21 +371,22 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
         hsw::ExpandParams p{};
         p.blocks = d_blocks + 64 * done;
         p.pre_states = d_pre_states + 8 * done;
-        p.gate = want_gate ? static_cast<uint8_t *>(d_gate) + (size_t)HSW_CELL_BYTES * G * done : nullptr;
+        p.gate = want_gate ? static_cast<uint8_t *>(d_gate) + cb * G * done : nullptr;
         p.chip_dense = d_chip_dense;
         p.chip_spread = d_chip_spread;
         p.next_states = d_next_states ? d_next_states + 8 * done : nullptr;
         p.lookup = args->d_lookup ? static_cast<uint8_t *>(args->d_lookup) +
-                                        (size_t)HSW_CELL_BYTES * e->shape.lookup_cells_per_block * done
+                                        cb * e->shape.lookup_cells_per_block * done
                                   : nullptr;
         p.n_blocks = n;
         p.chip_col_stride = chip_col_stride;
         p.cursor0 = spread_cursor0;
         p.ncols = e->shape.num_advice_columns;
         p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP) |
-                  ((flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY ? hsw::HSW_K_MONTGOMERY : 0u) |
+                  ((flags & HSW_REPR_MONTGOMERY) ? hsw::HSW_K_MONTGOMERY : 0u) |
+                  ((flags & HSW_REPR_COMPACT64) ? hsw::HSW_K_COMPACT : 0u) |
                   (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u);
-        const int tile = choose_tile(e, (flags & HSW_REPR_MASK) == HSW_REPR_MONTGOMERY);
+        const int tile = choose_tile(e, (flags & HSW_REPR_MONTGOMERY) != 0);
         p.parts = (uint32_t)choose_parts(e, n_blocks, tile);
         if (args->pack) {
             // breaks are given in call-relative stream indices; this launch starts at cell done*G
@@ -385,8 +405,8 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
             const uint64_t row_shift = c1 / nc - spread_cursor0 / nc;
             p.cursor0 = c1;
             if (want_chip) {
-                p.chip_dense = static_cast<uint8_t *>(d_chip_dense) + (size_t)row_shift * HSW_CELL_BYTES;
-                p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES;
+                p.chip_dense = static_cast<uint8_t *>(d_chip_dense) + (size_t)row_shift * cb;
+                p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * cb;
             }
         }
         he = hsw::launch_expand(p, e->limbs, tile, e->stream);
@@ -498,6 +518,7 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
     const size_t G = e->shape.gate_cells_per_block, LC = e->shape.limb_calls_per_block;
     const size_t ncols = e->shape.num_advice_columns;
     const bool want_gate = !(flags & HSW_SKIP_GATE), want_chip = !(flags & HSW_SKIP_CHIP);
+    const size_t cb = hsw_cell_bytes(flags);     // staging slots are sized for 32-byte cells either way
     size_t CH = 128;
     CH = ncols <= 64 ? CH - CH % ncols : ncols;            // chunk * LC must be a multiple of ncols
     if (CH > n_blocks) CH = ((n_blocks + ncols - 1) / ncols) * ncols;
@@ -528,9 +549,9 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
     const size_t rows_total = (size_t)hsw_chip_rows(&e->shape, cursor0, n_blocks);
     bool pinned_gate = false, pinned_cd = false, pinned_cs = false;
     if (pin) {   // pin the caller's buffers in place so the DMA engines can write them directly
-        if (want_gate) pinned_gate = hipHostRegister(gate, n_blocks * G * HSW_CELL_BYTES, hipHostRegisterDefault) == hipSuccess;
+        if (want_gate) pinned_gate = hipHostRegister(gate, n_blocks * G * cb, hipHostRegisterDefault) == hipSuccess;
         if (want_chip) {
-            const size_t span = ((ncols - 1) * chip_col_stride + rows_total) * HSW_CELL_BYTES;
+            const size_t span = ((ncols - 1) * chip_col_stride + rows_total) * cb;
             pinned_cd = hipHostRegister(chip_dense, span, hipHostRegisterDefault) == hipSuccess;
             pinned_cs = hipHostRegister(chip_spread, span, hipHostRegisterDefault) == hipSuccess;
         }
@@ -556,16 +577,16 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
             if (rc != HSW_OK) break;
             if ((he = hipEventRecord(s.kernel_done, e->stream)) != hipSuccess) { fail("record kernel_done"); break; }
             if ((he = hipStreamWaitEvent(e->copy_stream, s.kernel_done, 0)) != hipSuccess) { fail("wait kernel_done"); break; }
-            if (want_gate && (he = hipMemcpyAsync(static_cast<uint8_t *>(gate) + done * G * HSW_CELL_BYTES, s.gate,
-                                                  nb * G * HSW_CELL_BYTES, hipMemcpyDeviceToHost, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
+            if (want_gate && (he = hipMemcpyAsync(static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
+                                                  nb * G * cb, hipMemcpyDeviceToHost, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
             if (want_chip) {
                 for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
-                    const size_t dst = (c * chip_col_stride + row_off) * HSW_CELL_BYTES, src = c * e->slot_rows * HSW_CELL_BYTES;
+                    const size_t dst = (c * chip_col_stride + row_off) * cb, src = c * e->slot_rows * cb;
                     he = hipMemcpyAsync(static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
-                                        rows * HSW_CELL_BYTES, hipMemcpyDeviceToHost, e->copy_stream);
+                                        rows * cb, hipMemcpyDeviceToHost, e->copy_stream);
                     if (he == hipSuccess)
                         he = hipMemcpyAsync(static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
-                                            rows * HSW_CELL_BYTES, hipMemcpyDeviceToHost, e->copy_stream);
+                                            rows * cb, hipMemcpyDeviceToHost, e->copy_stream);
                 }
                 if (he != hipSuccess) { fail("D2H chip columns"); break; }
             }
@@ -610,6 +631,7 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
     const size_t rows = (size_t)hsw_chip_rows(&e->shape, spread_cursor0, n_blocks);
     if (!(flags & HSW_SKIP_CHIP) && chip_col_stride < rows)
         return set_err(e, HSW_ERR_INVALID_ARG, "chip_col_stride smaller than hsw_chip_rows()");
+    const size_t cb = hsw_cell_bytes(flags);
     const bool pin = (flags & HSW_HOST_REGISTER) != 0;
     flags &= ~HSW_HOST_REGISTER;
     // Chip rows of consecutive chunks do not share a row when the cursor is a
@@ -617,8 +639,8 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
     if (spread_cursor0 % ncols == 0)
         return pipelined_to_host(e, blocks, pre_states, n_blocks, spread_cursor0, gate, chip_dense, chip_spread,
                                  chip_col_stride, next_states, flags, pin);
-    const size_t gate_bytes = (flags & HSW_SKIP_GATE) ? 0 : n_blocks * G * HSW_CELL_BYTES;
-    const size_t col_bytes = (flags & HSW_SKIP_CHIP) ? 0 : ncols * rows * HSW_CELL_BYTES;
+    const size_t gate_bytes = (flags & HSW_SKIP_GATE) ? 0 : n_blocks * G * cb;
+    const size_t col_bytes = (flags & HSW_SKIP_CHIP) ? 0 : ncols * rows * cb;
 
     uint8_t *d_blocks = nullptr; uint32_t *d_pre = nullptr, *d_next = nullptr;
     void *d_gate = nullptr, *d_cd = nullptr, *d_cs = nullptr;
@@ -637,13 +659,13 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
         if (col_bytes) {
             // cells of the first / last row owned by neighbouring calls must survive the round trip
             for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
-                he = hipMemcpyAsync((uint8_t *)d_cd + c * rows * HSW_CELL_BYTES,
-                                    (const uint8_t *)chip_dense + c * chip_col_stride * HSW_CELL_BYTES,
-                                    rows * HSW_CELL_BYTES, hipMemcpyHostToDevice, e->stream);
+                he = hipMemcpyAsync((uint8_t *)d_cd + c * rows * cb,
+                                    (const uint8_t *)chip_dense + c * chip_col_stride * cb,
+                                    rows * cb, hipMemcpyHostToDevice, e->stream);
                 if (he == hipSuccess)
-                    he = hipMemcpyAsync((uint8_t *)d_cs + c * rows * HSW_CELL_BYTES,
-                                        (const uint8_t *)chip_spread + c * chip_col_stride * HSW_CELL_BYTES,
-                                        rows * HSW_CELL_BYTES, hipMemcpyHostToDevice, e->stream);
+                    he = hipMemcpyAsync((uint8_t *)d_cs + c * rows * cb,
+                                        (const uint8_t *)chip_spread + c * chip_col_stride * cb,
+                                        rows * cb, hipMemcpyHostToDevice, e->stream);
             }
             if (he != hipSuccess) { fail("H2D chip columns"); break; }
         }
@@ -652,12 +674,12 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
         if (gate_bytes && (he = hipMemcpyAsync(gate, d_gate, gate_bytes, hipMemcpyDeviceToHost, e->stream)) != hipSuccess) { fail("D2H gate"); break; }
         if (col_bytes) {
             for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
-                he = hipMemcpyAsync((uint8_t *)chip_dense + c * chip_col_stride * HSW_CELL_BYTES,
-                                    (uint8_t *)d_cd + c * rows * HSW_CELL_BYTES, rows * HSW_CELL_BYTES,
+                he = hipMemcpyAsync((uint8_t *)chip_dense + c * chip_col_stride * cb,
+                                    (uint8_t *)d_cd + c * rows * cb, rows * cb,
                                     hipMemcpyDeviceToHost, e->stream);
                 if (he == hipSuccess)
-                    he = hipMemcpyAsync((uint8_t *)chip_spread + c * chip_col_stride * HSW_CELL_BYTES,
-                                        (uint8_t *)d_cs + c * rows * HSW_CELL_BYTES, rows * HSW_CELL_BYTES,
+                    he = hipMemcpyAsync((uint8_t *)chip_spread + c * chip_col_stride * cb,
+                                        (uint8_t *)d_cs + c * rows * cb, rows * cb,
                                         hipMemcpyDeviceToHost, e->stream);
             }
             if (he != hipSuccess) { fail("D2H chip columns"); break; }

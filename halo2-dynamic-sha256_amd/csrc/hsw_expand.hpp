@@ -177,10 +177,14 @@ DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
 // rest is wave-uniform.  WHERE a cell goes inside the tile is not state at all:
 // it is the compile-time cursor type below, so every emitted cell is one
 // ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
-template <int T, int R, bool MONT_, bool RC_>
+// REPR: 0 = canonical 32-byte cells, 1 = Montgomery 32-byte cells, 2 = compact 8-byte cells
+// (low 64 bits; the negation cells hold x where the field value is -x -- hsw.h HSW_REPR_COMPACT64).
+template <int T, int R, int REPR_, bool RC_>
 struct Em {
     static constexpr int TILE = T, ROWS = R;
-    static constexpr bool MONT = MONT_;
+    static constexpr int REPR = REPR_;
+    static constexpr bool MONT = REPR_ == 1;
+    static constexpr bool COMPACT = REPR_ == 2;
     static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
     u64 *row;          // this lane's tile row (LDS)
     const u64 *tile;   // tile base (LDS)
@@ -225,7 +229,19 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, int na, int nb, int nc, i
     __syncthreads();
     const u32 lane = threadIdx.x;
     if (em.write_gate) {
-        if constexpr (EM::MONT) {
+        if constexpr (EM::COMPACT) {
+            // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction
+            (void)na; (void)nb; (void)nc; (void)nd;          // neg cells keep x (their positions are static: hsw_neg_cells)
+            u64 *out64 = reinterpret_cast<u64 *>(em.out);    // em.out was set up in 8-byte units for this mode
+            const u32 total = em.nrows * ncells;
+#pragma unroll 4
+            for (u32 i = lane; i < total; i += 64) {
+                const u32 r = i / ncells;
+                const u32 p = i - r * ncells;
+                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                out64[(size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)] = em.tile[r * (T + 1) + p];
+            }
+        } else if constexpr (EM::MONT) {
             const u32 total = em.nrows * ncells;
             for (u32 i = lane; i < total; i += 64) {
                 const u32 r = i / ncells;
@@ -358,7 +374,17 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
         const u32 count = (u32)(row_hi - row_lo + 1);
         const u32 n0 = (u32)(row_lo * ncols + c - first);              // run-relative limb index of row_lo
         const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
-        if constexpr (EM::MONT) {
+        if constexpr (EM::COMPACT) {
+            u64 *cd64 = reinterpret_cast<u64 *>(p.chip_dense) + (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
+            u64 *cs64 = reinterpret_cast<u64 *>(p.chip_spread) + (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
+            for (u32 k = lane; k < count; k += 64) {
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                cd64[k] = limb;
+                cs64[k] = spread16(limb);
+            }
+        } else if constexpr (EM::MONT) {
             for (u32 k = lane; k < count; k += 64) {
                 const u32 n = n0 + k * (u32)ncols;
                 const u32 call = n / L, j = n % L;
@@ -394,7 +420,10 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
     __syncthreads();
     const u32 lane = threadIdx.x;
     uint4 *out = reinterpret_cast<uint4 *>(p.lookup) + (lookup_block_base + em.lk_first) * 2u;
-    if constexpr (EM::MONT) {
+    if constexpr (EM::COMPACT) {
+        u64 *out64 = reinterpret_cast<u64 *>(p.lookup) + lookup_block_base + em.lk_first;
+        for (u32 k = lane; k < em.lks; k += 64) out64[k] = em.lk16[k];
+    } else if constexpr (EM::MONT) {
         for (u32 k = lane; k < em.lks; k += 64) {
             const Fe8 m = mont_from_u64<false>(em.lk16[k], 0);
             out[2 * k] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
@@ -710,7 +739,7 @@ DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
 // --------------------------------------------------------------- the kernel
 // T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
 // units one wave expands per phase; a block needs parts >= 64/R waves.
-template <int L, int T, int R, bool MONT, bool RC>
+template <int L, int T, int R, int REPR, bool RC>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     using LY = Lay<L, RC>;
     static_assert(R * (T + 1) * 8 >= 800, "tile must be able to hold the chain seeds");
@@ -784,7 +813,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
     __syncthreads();           // seeds are in registers: the tile may now overwrite them
 
-    using EM = Em<T, R, MONT, RC>;
+    using EM = Em<T, R, REPR, RC>;
     EM em;
     em.lk16 = s_lk16;
     em.tile = s_tile;
@@ -803,7 +832,10 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
                 else { em.brk2 = (u32)(bc - first); em.gap2 = (u32)p.break_gap[k]; }
             }
         }
-        em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)(first + gap0) * 2u;
+        if constexpr (REPR == 2)   // compact: 8-byte cells
+            em.out = reinterpret_cast<uint4 *>(reinterpret_cast<u64 *>(p.gate) + (size_t)(first + gap0));
+        else
+            em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)(first + gap0) * 2u;
     }
     const size_t lk_blk = (size_t)blk * (size_t)LY::LOOKUP_CELLS;
     em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
@@ -892,9 +924,11 @@ static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
     if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
     const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
     if (p.flags & HSW_K_MONTGOMERY)
-        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, true, RC>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 1, RC>), grid, block, 0, stream, p);
+    else if (p.flags & HSW_K_COMPACT)
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 2, RC>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, false, RC>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 0, RC>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -254,10 +254,11 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
         // Column buffers are addressed from absolute row 0 (cursor origin of the context).
         const uint64_t row_shift = ctx.num_limb_sum / ctx.shape.num_advice_columns;
+        const size_t cb = hsw_cell_bytes(ctx.repr_flags);
         rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
-                                static_cast<uint8_t *>(ctx.d_gate) + b0 * G * HSW_CELL_BYTES,
-                                static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * HSW_CELL_BYTES,
-                                static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * HSW_CELL_BYTES,
+                                static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb,
+                                static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb,
+                                static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb,
                                 ctx.chip_col_stride, d_next, ctx.repr_flags);
         if (rc != HSW_OK) break;
         if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
@@ -403,7 +404,9 @@ int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t 
 }
 
 int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) {
-    if (!g || (repr & ~HSW_REPR_MASK)) return HSW_ERR_INVALID_ARG;
+    if (!g || (repr & ~HSW_REPR_MASK) || repr == HSW_REPR_MASK) return HSW_ERR_INVALID_ARG;
+    if (g->ctx->blocks_done != 0 && hsw_cell_bytes(repr) != hsw_cell_bytes(g->ctx->repr_flags))
+        return HSW_ERR_INVALID_ARG;               // the cell size of a context's streams cannot change midway
     g->ctx->repr_flags = repr;
     return HSW_OK;
 }

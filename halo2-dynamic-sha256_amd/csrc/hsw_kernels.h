@@ -13,6 +13,7 @@ enum : uint32_t {
     HSW_K_MONTGOMERY = 1u,   // mirrors HSW_REPR_MONTGOMERY
     HSW_K_SKIP_GATE = 2u,    // mirrors HSW_SKIP_GATE
     HSW_K_SKIP_CHIP = 4u,    // mirrors HSW_SKIP_CHIP
+    HSW_K_COMPACT = 8u,      // HSW_REPR_COMPACT64: 8-byte cells
     HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
 };
 enum { HSW_K_MAX_BREAKS = 8 };

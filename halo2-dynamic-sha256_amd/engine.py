@@ -77,13 +77,15 @@ class WitnessEngine:
     def chip_rows(self, cursor0, n_blocks):
         return int(self.lib.hsw_chip_rows(C.byref(self.shape), cursor0, n_blocks))
 
-    def alloc_outputs(self, n_blocks, cursor0=0):
-        """Allocate the three output buffers for n_blocks blocks in HBM."""
+    def alloc_outputs(self, n_blocks, cursor0=0, flags=0):
+        """Allocate the three output buffers for n_blocks blocks in HBM (cells are
+        4 x int64, or 1 x int64 with HSW_REPR_COMPACT64)."""
         t = self.torch
         rows = self.chip_rows(cursor0, n_blocks)
-        gate = t.empty((n_blocks * self.G, 4), dtype=t.int64, device=self.device)
-        dense = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
-        spread = t.zeros((self.ncols, max(rows, 1), 4), dtype=t.int64, device=self.device)
+        w = 1 if (flags & N.HSW_REPR_COMPACT64) else 4
+        gate = t.empty((n_blocks * self.G, w), dtype=t.int64, device=self.device)
+        dense = t.zeros((self.ncols, max(rows, 1), w), dtype=t.int64, device=self.device)
+        spread = t.zeros((self.ncols, max(rows, 1), w), dtype=t.int64, device=self.device)
         nxt = t.empty((n_blocks, 8), dtype=t.int32, device=self.device)
         return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, rows=rows)
 
@@ -97,7 +99,7 @@ class WitnessEngine:
         n = blocks.numel() // 64
         assert pre_states.numel() == 8 * n
         if out is None:
-            out = self.alloc_outputs(n, cursor0)
+            out = self.alloc_outputs(n, cursor0, flags)
         gate, dense, spread, nxt = out["gate"], out["dense"], out["spread"], out["next_states"]
         rc = self.lib.hsw_witness_blocks(
             self.h, blocks.data_ptr(), pre_states.data_ptr(), n, cursor0,
@@ -147,7 +149,8 @@ class WitnessEngine:
         pre_states = np.ascontiguousarray(pre_states, dtype=np.uint32).reshape(-1, 8)
         n = blocks.shape[0]
         rows = self.chip_rows(cursor0, n)
-        shapes = dict(gate=(n * self.G, 4), dense=(self.ncols, rows, 4), spread=(self.ncols, rows, 4))
+        w = 1 if (flags & N.HSW_REPR_COMPACT64) else 4
+        shapes = dict(gate=(n * self.G, w), dense=(self.ncols, rows, w), spread=(self.ncols, rows, w))
         out, keep = {}, []
         for k, shp in shapes.items():
             nbytes = int(np.prod(shp)) * 8

@@ -59,7 +59,13 @@ extern "C" {
 /* ---- flags for hsw_witness_blocks ---- */
 #define HSW_REPR_CANONICAL     0u  /* cells hold the canonical integer, LE limbs */
 #define HSW_REPR_MONTGOMERY    1u  /* cells hold x*2^256 mod p (halo2curves Fr memory form) */
-#define HSW_REPR_MASK          1u
+#define HSW_REPR_COMPACT64    16u  /* transport form: 8-byte cells holding the low 64 bits of the canonical
+                                      value.  Every cell of the path fits 64 bits except the field negations
+                                      of ch (compression.rs:320-335; 256 cells per block at fixed positions,
+                                      hsw_neg_cells): those hold x where the cell's value is -x = p - x.
+                                      4x fewer bytes for PCIe-bound consumers; buffers are sized with
+                                      hsw_cell_bytes(flags) = 8 instead of 32 */
+#define HSW_REPR_MASK          (1u | 16u)
 #define HSW_SKIP_GATE          2u  /* do not write the gate stream (d_gate may be NULL) */
 #define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
 
@@ -119,6 +125,13 @@ int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, ui
 /* SpreadConfig::load (spread.rs:165-194): the 2^num_bits_lookup rows
  * (i, spread(i)) of the lookup table, as u64 values.  Either output may be NULL. */
 int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out);
+
+/* Bytes per cell for a flags word: 8 with HSW_REPR_COMPACT64, else 32. */
+uint32_t hsw_cell_bytes(uint32_t flags);
+/* Block-relative gate-stream indices of the cells that hold a field negation
+ * (4 per round, compression.rs:320-335), ascending; needed to decode
+ * HSW_REPR_COMPACT64.  out may be NULL to query the count (256). */
+int hsw_neg_cells(const hsw_shape *shape, uint32_t *out, size_t cap, size_t *n);
 
 /* Number of rows every chip column buffer must hold for n_blocks blocks whose
  * first limb call is #spread_cursor0: buffer row 0 is absolute chip row

@@ -20,6 +20,7 @@ pub const HSW_REPR_MONTGOMERY: u32 = 1;
 pub const HSW_SKIP_GATE: u32 = 2;
 pub const HSW_SKIP_CHIP: u32 = 4;
 pub const HSW_HOST_REGISTER: u32 = 8;
+pub const HSW_REPR_COMPACT64: u32 = 16;
 pub const HSW_MODE_DEFAULT: u32 = 0;
 pub const HSW_MODE_HALO2_INTERNALS: u32 = 1;
 pub const HSW_MAX_BREAKS: usize = 8;
@@ -125,6 +126,8 @@ extern "C" {
     pub fn hsw_shape_query(num_bits_lookup: u32, num_advice_columns: u32, out: *mut hsw_shape) -> c_int;
     pub fn hsw_shape_query_ex(num_bits_lookup: u32, num_advice_columns: u32, mode: u32, out: *mut hsw_shape) -> c_int;
     pub fn hsw_spread_table(num_bits_lookup: u32, dense_out: *mut u64, spread_out: *mut u64) -> c_int;
+    pub fn hsw_cell_bytes(flags: u32) -> u32;
+    pub fn hsw_neg_cells(shape: *const hsw_shape, out: *mut u32, cap: usize, n: *mut usize) -> c_int;
     pub fn hsw_chip_rows(shape: *const hsw_shape, spread_cursor0: u64, n_blocks: u64) -> u64;
 
     pub fn hsw_engine_create(device: c_int, hip_stream: *mut c_void, num_bits_lookup: u32,

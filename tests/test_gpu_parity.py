@@ -355,3 +355,52 @@ def test_two_engines_two_streams_concurrently(hsw, oracle):
     assert np.array_equal(o2["spread"].cpu().numpy().view(np.uint64), r2["spread"])
     e1.close()
     e2.close()
+
+
+def _compact_expected(oracle, hsw, ref, shape, n_blocks):
+    """HSW_REPR_COMPACT64 image of the oracle's canonical streams: low 64 bits, except the negation
+    cells (hsw_neg_cells) which hold x for the value p - x."""
+    P0 = 0x43e1f593f0000001
+    G = int(shape.gate_cells_per_block)
+    g = ref["gate"][:, 0].copy().reshape(n_blocks, G)
+    neg = hsw._native.neg_cells(shape).astype(np.int64)
+    assert len(neg) == 256
+    wide = (ref["gate"][:, 1:] != 0).any(axis=1).reshape(n_blocks, G)
+    # every > 64-bit cell of the path is one of the negation cells
+    mask = np.zeros(G, dtype=bool)
+    mask[neg] = True
+    assert not wide[:, ~mask].any()
+    vals = g[:, neg]
+    x = (np.uint64(P0) - vals).astype(np.uint64)           # p - (p - x) = x on the low limb (no borrow)
+    g[:, neg] = np.where(wide[:, neg], x, vals)            # neg(0) = 0 stays 0
+    return g.reshape(-1, 1), ref["dense"][..., :1], ref["spread"][..., :1]
+
+
+@pytest.mark.parametrize("bits,ncols,cursor0", [(8, 2, 0), (8, 3, 4), (16, 1, 0), (4, 2, 1)])
+def test_compact64_representation(engine_factory, oracle, hsw, bits, ncols, cursor0):
+    eng = engine_factory(bits, ncols)
+    blocks, pre = _rand_inputs(4, 800 + bits)
+    blocks[0] = 0
+    pre[0] = 0
+    ref = oracle.Oracle(bits, ncols, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
+    got = _run_gpu(eng, blocks, pre, cursor0=cursor0, flags=hsw.HSW_REPR_COMPACT64)
+    eg, ed, es = _compact_expected(oracle, hsw, ref, eng.shape, 4)
+    assert got["gate"].shape[1] == 1
+    assert np.array_equal(got["gate"].view(np.uint64), eg)
+    assert np.array_equal(got["dense"].view(np.uint64), ed) and np.array_equal(got["spread"].view(np.uint64), es)
+    assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])
+
+
+def test_compact64_host_delivery_and_flag_errors(engine_factory, oracle, hsw):
+    eng = engine_factory(8, 2)
+    blocks, pre = _rand_inputs(150, 4711)
+    got = eng.witness_blocks_host(blocks, pre, cursor0=0, flags=hsw.HSW_REPR_COMPACT64, pinned=True)
+    ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, pre)
+    eg, ed, es = _compact_expected(oracle, hsw, ref, eng.shape, 150)
+    assert np.array_equal(got["gate"], eg) and np.array_equal(got["dense"], ed) and np.array_equal(got["spread"], es)
+    import torch
+    b = torch.zeros((1, 64), dtype=torch.uint8, device="cuda")
+    p = torch.zeros((1, 8), dtype=torch.int32, device="cuda")
+    with pytest.raises(hsw.HswError):
+        eng.witness_blocks(b, p, flags=hsw.HSW_REPR_COMPACT64 | hsw.HSW_REPR_MONTGOMERY)
+    assert eng.lib.hsw_cell_bytes(hsw.HSW_REPR_COMPACT64) == 8 and eng.lib.hsw_cell_bytes(0) == 32
