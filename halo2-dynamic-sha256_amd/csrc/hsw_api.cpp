@@ -84,20 +84,24 @@ int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSucc
 //  * tile: cells per contiguous run of one unit.  Measured on MI355X (tools/ab.py,
 //    interleaved in one process, 4,096 blocks): canonical output is ~3 % faster
 //    with [32 rows][64 cells] tiles and 4 waves per block than with [64][32] and
-//    one wave; Montgomery output ~5 % faster with [16][128] tiles and 4 waves.
+//    one wave; Montgomery output ~5 % faster with [16][128] tiles and 4 waves;
+//    the 8-byte compact form (instruction-bound) ~8 % faster with [16][64] and 8.
 //  * parts: a block is 64 + 48 + ... independent units; one wave can expand all
 //    of them (lane = unit) or they can be dealt to 2..16 waves.  Small batches
 //    (e.g. the 16-block message of BASELINE configs[1]) need the split to
 //    occupy 256 CUs.
-int choose_tile(const hsw_engine *e, bool mont) {
-    if (e->limbs != 2) return 32;                 // wide tiles are built for the 8-bit table only
+int choose_tile(const hsw_engine *e, uint32_t flags) {
+    if (e->limbs != 2) return 32;                 // other tile shapes are built for the 8-bit table only
     if (e->tile > 0) return e->tile;
-    return mont ? 128 : 64;
+    if (flags & HSW_REPR_COMPACT64) return 6416;  // [16 rows][64 cells]: not HBM-bound, wants many small waves
+    return (flags & HSW_REPR_MONTGOMERY) ? 128 : 64;
 }
-int choose_parts(const hsw_engine *e, size_t n_blocks, int tile) {
-    const int min_parts = tile / 32;              // a T-cell tile has 64*32/T rows: [64][32] [32][64] [16][128]
+int choose_parts(const hsw_engine *e, size_t n_blocks, int tile, uint32_t flags = 0) {
+    // a T-cell tile has 64*32/T rows: [64][32] [32][64] [16][128]; experimental codes TTRR: [32][32] [16][32] [16][64]
+    const int min_parts = tile == 3232 ? 2 : (tile == 3216 || tile == 6416) ? 4 : tile / 32;
     if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
-    int parts = tile >= 64 ? 4 : min_parts;
+    int parts = (flags & HSW_REPR_COMPACT64) ? 8 : ((tile >= 64 && tile < 1000) ? 4 : min_parts);
+    if (parts < min_parts) parts = min_parts;
     while (parts < 16 && n_blocks * (size_t)parts < 2048) parts *= 2;
     return parts < min_parts ? min_parts : parts;
 }
@@ -282,7 +286,7 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         return HSW_OK;
     }
     if (std::strcmp(name, "tile") == 0) {
-        if (value != 0 && value != 32 && value != 64 && value != 128)
+        if (value != 0 && value != 32 && value != 64 && value != 128 && value != 3232 && value != 3216 && value != 6416)
             return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 0 (auto), 32, 64 or 128");
         e->tile = (int)value;
         return HSW_OK;
@@ -386,8 +390,8 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
                   ((flags & HSW_REPR_MONTGOMERY) ? hsw::HSW_K_MONTGOMERY : 0u) |
                   ((flags & HSW_REPR_COMPACT64) ? hsw::HSW_K_COMPACT : 0u) |
                   (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u);
-        const int tile = choose_tile(e, (flags & HSW_REPR_MONTGOMERY) != 0);
-        p.parts = (uint32_t)choose_parts(e, n_blocks, tile);
+        const int tile = choose_tile(e, flags);
+        p.parts = (uint32_t)choose_parts(e, n_blocks, tile, flags);
         if (args->pack) {
             // breaks are given in call-relative stream indices; this launch starts at cell done*G
             for (uint32_t k = 0; k < args->pack->n_breaks; k++) {

@@ -941,6 +941,9 @@ hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) 
         else return hipErrorInvalidValue;
     }
     switch (tile) {
+        case 3232: if constexpr (L == 2) return launch_expand_LTR<L, 32, 32, false>(p, stream); else return hipErrorInvalidValue;
+        case 3216: if constexpr (L == 2) return launch_expand_LTR<L, 32, 16, false>(p, stream); else return hipErrorInvalidValue;
+        case 6416: if constexpr (L == 2) return launch_expand_LTR<L, 64, 16, false>(p, stream); else return hipErrorInvalidValue;
         case 32: return launch_expand_LTR<L, 32, 64, false>(p, stream);
         case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32, false>(p, stream); else return hipErrorInvalidValue;
         case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16, false>(p, stream); else return hipErrorInvalidValue;

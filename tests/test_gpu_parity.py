@@ -244,7 +244,8 @@ def test_montgomery_representation(engine_factory, oracle, hsw, bits, ncols, cur
 
 
 @pytest.mark.parametrize("tile,parts", [(32, 1), (32, 2), (32, 4), (32, 8), (32, 16), (32, 32), (64, 2), (64, 4),
-                                        (64, 16), (64, 32), (128, 4), (128, 8), (128, 16), (128, 32), (0, 0)])
+                                        (64, 16), (64, 32), (128, 4), (128, 8), (128, 16), (128, 32), (3232, 2),
+                                        (3216, 4), (6416, 8), (0, 0)])
 @pytest.mark.parametrize("mont", [False, True])
 def test_every_tile_shape_and_split_gives_identical_streams(engine_factory, oracle, hsw, tile, parts, mont):
     """Tuning knobs never change results: every (tile, waves-per-block) combination,
