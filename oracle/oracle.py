@@ -27,15 +27,35 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+def _cpu_signature():
+    """ISA flags of this host: liboracle.so is built with -march=native, so a
+    library built on another machine (the build container vs the GPU box) must
+    be rebuilt before it is loaded."""
+    try:
+        import hashlib
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return hashlib.sha256(line.encode()).hexdigest()[:16]
+    except Exception:
+        pass
+    return "unknown"
+
+
 def build(force=False):
     """Compile liboracle.so with the committed Makefile (gcc only)."""
     src = os.path.join(_HERE, "hsw_oracle.c")
-    if (force or not os.path.exists(_LIB_PATH)
+    stamp = os.path.join(_HERE, ".build_host")
+    sig = _cpu_signature()
+    try:
+        same_host = open(stamp).read().strip() == sig
+    except Exception:
+        same_host = False
+    if (force or not same_host or not os.path.exists(_LIB_PATH)
             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        # -march=native objects do not travel between machines: rebuild when
-        # the library is older than the source or missing.
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
         subprocess.check_call(["make", "-C", _HERE, "-s"])
+        with open(stamp, "w") as f:
+            f.write(sig)
     return _LIB_PATH
 
 
