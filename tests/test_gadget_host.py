@@ -52,3 +52,35 @@ def test_prepare_errors_mirror_reference_asserts(hsw):
         with pytest.raises(hsw.HswError) as ei:
             hsw.digest_prepare(*args)
         assert ei.value.status == status, args
+
+
+def test_prepare_property_random_shapes(hsw, oracle):
+    """Property test: for random (message length, maximum size, precomputed prefix) libhsw's host padding
+    equals the oracle's restatement of lib.rs:77-160, and chaining its blocks with plain SHA-256 from its
+    prefix state reproduces hashlib at the selected round (the "select state #n" rule, lib.rs:294-310)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(0, 700), st.integers(1, 12), st.integers(0, 8), st.integers(0, 2**32 - 1))
+    def prop(n, max_blocks, pre_blocks, seed):
+        msg = np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8).tobytes()
+        maxb, pre = 64 * max_blocks, 64 * pre_blocks
+        padded = ((n + 9 + 63) // 64) * 64
+        fits = pre <= padded and padded - pre <= maxb
+        if not fits:
+            with pytest.raises(hsw.HswError):
+                hsw.digest_prepare(msg, maxb, pre)
+            with pytest.raises(ValueError):
+                oracle.Oracle(8, 2).digest(msg, maxb, pre)
+            return
+        blocks, init, info = hsw.digest_prepare(msg, maxb, pre)
+        st_ = init.copy()
+        states = [st_.copy()]
+        for b in blocks.reshape(-1, 64):
+            st_ = oracle.plain_compress(st_, b)
+            states.append(st_.copy())
+        dig = b"".join(int(x).to_bytes(4, "big") for x in states[info["target_round"]])
+        assert dig == hashlib.sha256(msg).digest()
+        assert info["n_blocks"] == max_blocks and info["precomputed_round"] == pre_blocks
+
+    prop()
