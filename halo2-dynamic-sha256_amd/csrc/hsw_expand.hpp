@@ -222,68 +222,97 @@ using CurStart = Cur<0, 0>;
 // Transpose `ncells` tile columns out to HBM: row r goes to cells
 // [cell_base + r*unit_cells + seg, +ncells).  Canonical form: lane pairs cover one
 // 32-byte cell (low / high 16 bytes), so a wave-wide store instruction writes
-// 1 KiB contiguous.  Montgomery form: one lane per cell, two 16-byte stores.
+// 1 KiB contiguous.  Montgomery / compact form: one lane per cell.
+// All addressing is a wave-uniform base pointer plus a 32-bit byte offset (one
+// block's stream spans far less than 4 GiB even with column-break gaps), so a store costs a
+// handful of VALU instructions instead of 64-bit pointer arithmetic per lane.
 template <class EM>
+DEV u32 packed_cell(const EM &em, u32 cl) {       // FlexGate column packing: add the gaps of the breaks passed
+    return cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u);
+}
+DEV void store16(char *base, u32 byte_off, uint4 v) { *reinterpret_cast<uint4 *>(base + (size_t)byte_off) = v; }
+DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base + (size_t)byte_off) = v; }
+
+template <class EM, bool FULL>
 DEV void flush_tile(const EM &em, u32 ncells, u32 seg, int na, int nb, int nc, int nd) {
     constexpr int T = EM::TILE;
     __syncthreads();
     const u32 lane = threadIdx.x;
+    char *base = reinterpret_cast<char *>(em.out);
+    const bool packed = em.brk1 != 0xffffffffu;          // wave-uniform; false unless a pack plan is in force
     if (em.write_gate) {
         if constexpr (EM::COMPACT) {
-            // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction
-            (void)na; (void)nb; (void)nc; (void)nd;          // neg cells keep x (their positions are static: hsw_neg_cells)
-            u64 *out64 = reinterpret_cast<u64 *>(em.out);    // em.out was set up in 8-byte units for this mode
+            // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
+            // Negation cells keep x (their positions are static: hsw_neg_cells).
+            (void)na; (void)nb; (void)nc; (void)nd;
             const u32 total = em.nrows * ncells;
 #pragma unroll 4
             for (u32 i = lane; i < total; i += 64) {
-                const u32 r = i / ncells;
-                const u32 p = i - r * ncells;
-                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                out64[(size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)] = em.tile[r * (T + 1) + p];
+                const u32 r = FULL ? i / (u32)T : i / ncells;
+                const u32 p = FULL ? i % (u32)T : i - r * ncells;
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store8(base, cl * 8u, em.tile[r * (T + 1) + p]);
             }
         } else if constexpr (EM::MONT) {
             const u32 total = em.nrows * ncells;
             for (u32 i = lane; i < total; i += 64) {
-                const u32 r = i / ncells;
-                const u32 p = i - r * ncells;
+                const u32 r = FULL ? i / (u32)T : i / ncells;
+                const u32 p = FULL ? i % (u32)T : i - r * ncells;
                 const u64 v = em.tile[r * (T + 1) + p];
                 Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
                 if (na >= 0) {                        // compile-time: most tiles hold no neg cell
                     const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
                     if (isneg && v != 0ull) m = fe_neg_nonzero(m);
                 }
-                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                uint4 *dst = em.out + ((size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)) * 2u;
-                dst[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
-                dst[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store16(base, cl * 32u, make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]));
+                store16(base, cl * 32u + 16u, make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]));
+            }
+        } else if (FULL && !packed) {
+            // the common case: a full tile, no column break in this block.  Lane l owns the
+            // 16-byte piece (l & 1) of cell (l >> 1) + 32 k of every row; LDS and HBM
+            // addresses advance by constants.
+            const u32 h = lane & 1u, p0 = lane >> 1;
+            const u64 *src = em.tile + p0;
+            u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
+            const u32 row_bytes = em.unit_cells * 32u;
+            for (u32 r = 0; r < em.nrows; r++, src += T + 1, off += row_bytes) {
+#pragma unroll
+                for (int k = 0; k < T / 32; k++) {
+                    const u64 v = src[32 * k];
+                    const u32 lo = (u32)v, hi = (u32)(v >> 32);
+                    uint4 o = make_uint4(h ? 0u : lo, h ? 0u : hi, 0u, 0u);
+                    if (na >= 0) {
+                        const u32 p = p0 + 32u * (u32)k;
+                        const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
+                        if (isneg && v != 0ull)       // cell holds p - x (neg gate, compression.rs:320-321)
+                            o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
+                                  : make_uint4(HSW_P0 - lo, HSW_P1, HSW_P2, HSW_P3);
+                    }
+                    store16(base, off + 1024u * (u32)k, o);
+                }
             }
         } else {
             const u32 ppr = 2u * ncells;          // 16-byte pieces per row
             const u32 total = em.nrows * ppr;
-#pragma unroll 4
             for (u32 i = lane; i < total; i += 64) {
                 const u32 r = i / ppr;
                 const u32 q = i - r * ppr;
                 const u32 p = q >> 1, h = q & 1u;
                 const u64 v = em.tile[r * (T + 1) + p];
                 const u32 lo = (u32)v, hi = (u32)(v >> 32);
-                uint4 o;
-                o.x = h ? 0u : lo;
-                o.y = h ? 0u : hi;
-                o.z = 0u;
-                o.w = 0u;
-                if (na >= 0) {                        // compile-time: most tiles hold no neg cell
+                uint4 o = make_uint4(h ? 0u : lo, h ? 0u : hi, 0u, 0u);
+                if (na >= 0) {
                     const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
-                    if (isneg && v != 0ull) {
-                        // cell holds p - x (neg gate, compression.rs:320-321), x <= 0x55555555
-                        o.x = h ? HSW_P4 : (HSW_P0 - lo);
-                        o.y = h ? HSW_P5 : HSW_P1;
-                        o.z = h ? HSW_P6 : HSW_P2;
-                        o.w = h ? HSW_P7 : HSW_P3;
-                    }
+                    if (isneg && v != 0ull)
+                        o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
+                              : make_uint4(HSW_P0 - lo, HSW_P1, HSW_P2, HSW_P3);
                 }
-                const u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                em.out[((size_t)cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u)) * 2u + h] = o;
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store16(base, cl * 32u + h * 16u, o);
             }
         }
     }
@@ -294,7 +323,7 @@ template <class EM, class C>
 DEV auto emit(C, EM &em, u64 v) {
     em.row[C::pos] = v;
     if constexpr (C::pos + 1 == EM::TILE) {
-        flush_tile(em, EM::TILE, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
+        flush_tile<EM, true>(em, EM::TILE, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
         return Cur<0, C::fl + 1>{};
     } else {
         return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd>{};
@@ -364,8 +393,6 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
     const u64 first = block_first_limb + (u64)em.call_first * L;       // first limb call of this run
     const u64 last = first + (u64)em.calls * L - 1;
     const u64 row0 = p.cursor0 / ncols;
-    uint4 *cd = reinterpret_cast<uint4 *>(p.chip_dense);
-    uint4 *cs = reinterpret_cast<uint4 *>(p.chip_spread);
     for (u64 c = 0; c < ncols; c++) {
         if (last < c) continue;
         const u64 row_lo = (first + ncols - 1 - c) / ncols;            // first row with row*ncols + c >= first
@@ -373,16 +400,18 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
         if (row_hi < row_lo) continue;
         const u32 count = (u32)(row_hi - row_lo + 1);
         const u32 n0 = (u32)(row_lo * ncols + c - first);              // run-relative limb index of row_lo
-        const size_t base = ((size_t)c * p.chip_col_stride + (size_t)(row_lo - row0)) * 2u;
+        // wave-uniform column run base + 32-bit lane offsets
+        const size_t cell0 = (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
+        constexpr u32 CB = EM::COMPACT ? 8u : 32u;
+        char *cdb = reinterpret_cast<char *>(p.chip_dense) + cell0 * CB;
+        char *csb = reinterpret_cast<char *>(p.chip_spread) + cell0 * CB;
         if constexpr (EM::COMPACT) {
-            u64 *cd64 = reinterpret_cast<u64 *>(p.chip_dense) + (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
-            u64 *cs64 = reinterpret_cast<u64 *>(p.chip_spread) + (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
             for (u32 k = lane; k < count; k += 64) {
                 const u32 n = n0 + k * (u32)ncols;
                 const u32 call = n / L, j = n % L;
                 const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
-                cd64[k] = limb;
-                cs64[k] = spread16(limb);
+                store8(cdb, k * 8u, limb);
+                store8(csb, k * 8u, spread16(limb));
             }
         } else if constexpr (EM::MONT) {
             for (u32 k = lane; k < count; k += 64) {
@@ -390,10 +419,10 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
                 const u32 call = n / L, j = n % L;
                 const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
                 const Fe8 md = mont_from_u64<false>(limb, 0), ms = mont_from_u64<false>(spread16(limb), 0);
-                cd[base + 2 * k] = make_uint4(md.l[0], md.l[1], md.l[2], md.l[3]);
-                cd[base + 2 * k + 1] = make_uint4(md.l[4], md.l[5], md.l[6], md.l[7]);
-                cs[base + 2 * k] = make_uint4(ms.l[0], ms.l[1], ms.l[2], ms.l[3]);
-                cs[base + 2 * k + 1] = make_uint4(ms.l[4], ms.l[5], ms.l[6], ms.l[7]);
+                store16(cdb, k * 32u, make_uint4(md.l[0], md.l[1], md.l[2], md.l[3]));
+                store16(cdb, k * 32u + 16u, make_uint4(md.l[4], md.l[5], md.l[6], md.l[7]));
+                store16(csb, k * 32u, make_uint4(ms.l[0], ms.l[1], ms.l[2], ms.l[3]));
+                store16(csb, k * 32u + 16u, make_uint4(ms.l[4], ms.l[5], ms.l[6], ms.l[7]));
             }
         } else {
             for (u32 i = lane; i < 2u * count; i += 64) {
@@ -401,11 +430,8 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
                 const u32 n = n0 + k * (u32)ncols;
                 const u32 call = n / L, j = n % L;
                 const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
-                uint4 od, os;
-                od.x = hpart ? 0u : limb;            od.y = 0; od.z = 0; od.w = 0;
-                os.x = hpart ? 0u : spread16(limb);  os.y = 0; os.z = 0; os.w = 0;
-                cd[base + i] = od;
-                cs[base + i] = os;
+                store16(cdb, i * 16u, make_uint4(hpart ? 0u : limb, 0u, 0u, 0u));
+                store16(csb, i * 16u, make_uint4(hpart ? 0u : spread16(limb), 0u, 0u, 0u));
             }
         }
     }
@@ -442,7 +468,7 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
 
 template <int L, class EM, class C>
 DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
-    if constexpr (C::pos != 0) flush_tile(em, C::pos, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
+    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
     flush_chip<L>(em, p, block_first_limb);
     if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
 }
