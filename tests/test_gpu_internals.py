@@ -102,3 +102,47 @@ def test_flexgate_column_packing(hsw, oracle, eng_int, engine_factory, internals
     mask[idx] = False
     assert (flat[mask] == np.uint64(2**64 - 1)).all()
     assert plan.columns_touched == max(c for c, _ in pos) + 1
+
+
+@pytest.mark.parametrize("flags_name", ["HSW_REPR_MONTGOMERY", "HSW_REPR_COMPACT64"])
+def test_packing_combined_with_other_representations(hsw, oracle, eng_int, flags_name):
+    """Column packing + internals + a non-default cell representation in one call."""
+    import torch
+    flags = getattr(hsw, flags_name)
+    n, start_row, max_rows = 3, 777, 90001
+    blocks, pre = _inputs(n, 31)
+    ref = oracle.Oracle(8, 2, check=False, internals=True).witness_blocks(blocks, pre)
+    plan = hsw._native.pack_plan(eng_int.shape, n, start_row, max_rows)
+    width = 1 if flags == hsw.HSW_REPR_COMPACT64 else 4
+    gate = torch.full((int(plan.span_cells), width), -1, dtype=torch.int64, device="cuda")
+    lookup = torch.empty((n * 3184, width), dtype=torch.int64, device="cuda")
+    rows = eng_int.chip_rows(0, n)
+    dense = torch.zeros((2, rows, width), dtype=torch.int64, device="cuda")
+    spread = torch.zeros((2, rows, width), dtype=torch.int64, device="cuda")
+    import ctypes as C
+    a = hsw._native.WitnessArgs()
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    a.d_blocks, a.d_pre_states, a.n_blocks, a.spread_cursor0 = tb.data_ptr(), tp.data_ptr(), n, 0
+    a.d_gate, a.d_chip_dense, a.d_chip_spread, a.chip_col_stride = gate.data_ptr(), dense.data_ptr(), spread.data_ptr(), rows
+    a.d_next_states, a.d_lookup, a.flags, a.pack = None, lookup.data_ptr(), flags, C.pointer(plan)
+    rc = eng_int.lib.hsw_witness_blocks_ex(eng_int.h, C.byref(a))
+    assert rc == 0, eng_int.lib.hsw_last_error(eng_int.h)
+    eng_int.synchronize()
+    lens = hsw._native.gate_tape(eng_int.shape)
+    pos = _model_positions(lens, n, start_row, max_rows)
+    idx = np.array([c * max_rows + r - start_row for c, r in pos], dtype=np.int64)
+    flat = gate.cpu().numpy().view(np.uint64)
+    if flags == hsw.HSW_REPR_MONTGOMERY:
+        assert np.array_equal(flat[idx], oracle.to_montgomery(ref["gate"]))
+        assert np.array_equal(lookup.cpu().numpy().view(np.uint64), oracle.to_montgomery(ref["lookup"]))
+    else:
+        neg = hsw._native.neg_cells(eng_int.shape).astype(np.int64)
+        exp = ref["gate"][:, 0].copy().reshape(n, -1)
+        wide = (ref["gate"][:, 1:] != 0).any(axis=1).reshape(n, -1)
+        x = (np.uint64(0x43e1f593f0000001) - exp[:, neg]).astype(np.uint64)
+        exp[:, neg] = np.where(wide[:, neg], x, exp[:, neg])
+        assert np.array_equal(flat[idx, 0], exp.reshape(-1))
+        assert np.array_equal(lookup.cpu().numpy().view(np.uint64)[:, 0], ref["lookup"][:, 0])
+    mask = np.ones(flat.shape[0], dtype=bool)
+    mask[idx] = False
+    assert (flat[mask] == np.uint64(2**64 - 1)).all()
