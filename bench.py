@@ -167,7 +167,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("HSW_BENCH_FORCE_DIST") == "1"   # force: 1-rank RCCL rehearsal
     # Rehearsal knobs (not used by the driver): HSW_BENCH_BACKEND=gloo and HSW_BENCH_SAME_DEVICE=1 run
     # the multi-rank control flow on a box with ONE GPU (all ranks on cuda:0, collectives on the CPU).
     backend = os.environ.get("HSW_BENCH_BACKEND", "nccl")
