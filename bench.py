@@ -479,7 +479,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes; bytes per launch)" if traffic else None,
                 "calibrated_fill_GBps": fill_gbs,
-                "kernel": "hsw::hsw_expand_kernel<2, 64, 32, false, false> (64-cell tiles, 4 waves per block)",
+                "kernel": "hsw::hsw_expand_kernel<2, 64, 32, 0, false> (64-cell tiles, 4 waves per block)",
                 "kernel_ms": kernel_ms_avg,
                 "kernel_ms_engine_events": kernel_ms_engine,
                 "algorithmic_bytes_per_launch": alg_bytes * n,
