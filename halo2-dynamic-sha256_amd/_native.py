@@ -30,6 +30,8 @@ HSW_MODE_DEFAULT = 0
 HSW_MODE_HALO2_INTERNALS = 1
 HSW_MAX_BREAKS = 8
 HSW_CELL_BYTES = 32
+HSW_GADGET_WHOLE_DIGEST = 1
+NO_CELL = (1 << 64) - 1
 
 
 class Shape(C.Structure):
@@ -57,7 +59,24 @@ class WitnessArgs(C.Structure):
     _fields_ = [("d_blocks", C.c_void_p), ("d_pre_states", C.c_void_p), ("n_blocks", C.c_size_t),
                 ("spread_cursor0", C.c_uint64), ("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p),
                 ("d_chip_spread", C.c_void_p), ("chip_col_stride", C.c_size_t), ("d_next_states", C.c_void_p),
-                ("d_lookup", C.c_void_p), ("flags", C.c_uint32), ("pack", C.POINTER(PackPlan))]
+                ("d_lookup", C.c_void_p), ("flags", C.c_uint32), ("pack", C.POINTER(PackPlan)),
+                ("frame_every", C.c_uint64), ("frame_cells", C.c_uint64), ("frame_lookups", C.c_uint64)]
+
+
+class FrameShape(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_blocks", "prologue_cells", "epilogue_cells", "prologue_lookups", "epilogue_lookups",
+        "prologue_calls", "epilogue_calls", "digest_cells", "digest_lookups")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "input_len", "first_block", "prologue_cell", "epilogue_cell", "prologue_lookup",
+        "epilogue_lookup", "zero_cell")] + [(n, C.c_uint32) for n in (
+        "n_blocks", "num_round", "precomputed_round", "is_input_range_check")]
 
 
 class DigestInfo(C.Structure):
@@ -68,13 +87,17 @@ class DigestInfo(C.Structure):
 class HashResult(C.Structure):
     _fields_ = [("input_len", C.c_uint64), ("first_block", C.c_size_t), ("n_blocks", C.c_size_t),
                 ("spread_cursor0", C.c_uint64), ("num_round", C.c_size_t), ("target_round", C.c_size_t),
-                ("output_bytes", C.c_uint8 * 32)]
+                ("output_bytes", C.c_uint8 * 32)] + [(n, C.c_uint64) for n in (
+        "prologue_cell", "block_cell", "epilogue_cell", "end_cell",
+        "prologue_lookup", "block_lookup", "epilogue_lookup")]
 
 
 class GadgetView(C.Structure):
     _fields_ = [("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p), ("d_chip_spread", C.c_void_p),
                 ("d_next_states", C.c_void_p), ("chip_col_stride", C.c_size_t), ("blocks_done", C.c_size_t),
-                ("capacity_blocks", C.c_size_t), ("num_limb_sum", C.c_uint64), ("cur_hash_idx", C.c_size_t)]
+                ("capacity_blocks", C.c_size_t), ("num_limb_sum", C.c_uint64), ("cur_hash_idx", C.c_size_t),
+                ("gate_cells", C.c_uint64), ("gate_capacity", C.c_uint64), ("d_lookup", C.c_void_p),
+                ("lookup_cells", C.c_uint64), ("lookup_capacity", C.c_uint64)]
 
 
 # every symbol include/hsw.h declares (tests check the library exports them all)
@@ -88,6 +111,7 @@ SYMBOLS = (
     "hsw_gadget_set_repr", "hsw_download", "hsw_host_alloc", "hsw_host_free",
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
+    "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
 )
 
 
@@ -191,6 +215,16 @@ def lib():
         L.hsw_download.argtypes = [vp, vp, vp, C.c_size_t]
         L.hsw_gadget_set_repr.restype = C.c_int
         L.hsw_gadget_set_repr.argtypes = [vp, C.c_uint32]
+        L.hsw_frame_query.restype = C.c_int
+        L.hsw_frame_query.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_int, C.POINTER(FrameShape)]
+        L.hsw_frame_tape.restype = C.c_int
+        L.hsw_frame_tape.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
+        L.hsw_witness_frames.restype = C.c_int
+        L.hsw_witness_frames.argtypes = [vp, C.POINTER(FrameDesc), C.c_size_t, vp, vp, vp, vp, vp, C.c_uint32]
+        L.hsw_gadget_create_ex.restype = C.c_int
+        L.hsw_gadget_create_ex.argtypes = [vp, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_uint32,
+                                           C.POINTER(vp)]
     _lib = L
     return L
 
@@ -267,3 +301,28 @@ def pack_plan(shape, n_blocks, start_row, max_rows):
     if rc != HSW_OK:
         raise HswError(rc)
     return p
+
+
+def frame_query(shape, max_variable_byte_size, is_input_range_check=False):
+    """hsw_frame_query: cell counts of the digest frame."""
+    fs = FrameShape()
+    rc = lib().hsw_frame_query(C.byref(shape), max_variable_byte_size, 1 if is_input_range_check else 0, C.byref(fs))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return fs
+
+
+def frame_tape(shape, max_variable_byte_size, is_input_range_check, section):
+    """assign_region call lengths of the prologue (section 0) / epilogue (1), numpy uint8."""
+    import numpy as np
+    n = C.c_size_t()
+    rc = lib().hsw_frame_tape(C.byref(shape), max_variable_byte_size, 1 if is_input_range_check else 0, section,
+                              None, 0, C.byref(n))
+    if rc != HSW_OK:
+        raise HswError(rc)
+    lens = np.zeros(n.value, dtype=np.uint8)
+    rc = lib().hsw_frame_tape(C.byref(shape), max_variable_byte_size, 1 if is_input_range_check else 0, section,
+                              lens.ctypes.data, lens.size, None)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return lens

@@ -10,8 +10,11 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/hsw.h"
+#include "hsw_fr.hpp"
+#include "hsw_frame.hpp"
 #include "hsw_kernels.h"
 #include "hsw_layout.h"
 #include "hsw_tape.hpp"
@@ -36,6 +39,13 @@ struct hsw_engine {
         hipEvent_t kernel_done = nullptr, copy_done = nullptr;
     } slot[2];
     size_t slot_blocks = 0, slot_rows = 0;
+    // digest frames (hsw_witness_frames): descriptors staged per call, and k^-1 for
+    // k = 0..inv_n-1 in canonical ([0]) and Montgomery ([1]) form
+    hsw::FrameDesc *d_frame_descs = nullptr;
+    size_t frame_desc_cap = 0;
+    std::vector<hsw::FrameDesc> h_frame_descs;
+    uint64_t *d_inv_tbl[2] = {nullptr, nullptr};
+    size_t inv_n = 0;
 };
 
 namespace {
@@ -250,6 +260,9 @@ void hsw_engine_destroy(hsw_engine *e) {
     {
         DeviceScope ds(e->device);
         free_pipeline(e);
+        if (e->d_frame_descs) (void)hipFree(e->d_frame_descs);
+        if (e->d_inv_tbl[0]) (void)hipFree(e->d_inv_tbl[0]);
+        if (e->d_inv_tbl[1]) (void)hipFree(e->d_inv_tbl[1]);
         if (e->ev0) (void)hipEventDestroy(e->ev0);
         if (e->ev1) (void)hipEventDestroy(e->ev1);
     }
@@ -358,6 +371,14 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
         return set_err(e, HSW_ERR_INVALID_ARG, "lookup buffer not 16-byte aligned");
     if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS)
         return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    if (args->frame_every) {
+        if (e->mode != HSW_MODE_HALO2_INTERNALS)
+            return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
+        if (flags & HSW_REPR_COMPACT64)
+            return set_err(e, HSW_ERR_UNSUPPORTED, "digest frames hold full-width cells: no HSW_REPR_COMPACT64");
+        if (n_blocks > ((size_t)1 << 20))
+            return set_err(e, HSW_ERR_UNSUPPORTED, "more than 2^20 blocks in one framed call");
+    }
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
 
@@ -390,6 +411,9 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
                   ((flags & HSW_REPR_MONTGOMERY) ? hsw::HSW_K_MONTGOMERY : 0u) |
                   ((flags & HSW_REPR_COMPACT64) ? hsw::HSW_K_COMPACT : 0u) |
                   (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u);
+        p.frame_every = args->frame_every;
+        p.frame_cells = args->frame_cells;
+        p.frame_lookups = args->frame_lookups;
         const int tile = choose_tile(e, flags);
         p.parts = (uint32_t)choose_parts(e, n_blocks, tile, flags);
         if (args->pack) {
@@ -433,6 +457,145 @@ int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t 
         if (cap < lens.size()) return HSW_ERR_INVALID_ARG;
         std::memcpy(lens_out, lens.data(), lens.size());
     }
+    return HSW_OK;
+}
+
+// ------------------------------------------------------------ digest frames
+int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                    hsw_frame_shape *out) {
+    if (!shape || !out) return HSW_ERR_INVALID_ARG;
+    if (shape->mode != HSW_MODE_HALO2_INTERNALS) return HSW_ERR_INVALID_ARG;   // a frame is halo2-base internals
+    if (max_variable_byte_size % 64 != 0) return HSW_ERR_SHAPE;                 // lib.rs:57-59
+    const bool rc = is_input_range_check != 0;
+    const uint64_t nb = max_variable_byte_size / 64;
+    out->n_blocks = nb;
+    out->prologue_cells = hsw::frame::prologue_cells(max_variable_byte_size, rc);
+    out->epilogue_cells = hsw::frame::epilogue_cells(nb);
+    out->prologue_lookups = hsw::frame::prologue_lookups(max_variable_byte_size, rc);
+    out->epilogue_lookups = hsw::frame::E_LOOKUPS;
+    out->prologue_calls = hsw::frame::prologue_calls(max_variable_byte_size, rc);
+    out->epilogue_calls = hsw::frame::epilogue_calls(nb);
+    out->digest_cells = out->prologue_cells + nb * shape->gate_cells_per_block + out->epilogue_cells;
+    out->digest_lookups = out->prologue_lookups + nb * shape->lookup_cells_per_block + out->epilogue_lookups;
+    return HSW_OK;
+}
+
+int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                   int section, uint8_t *lens_out, size_t cap, size_t *n_calls) {
+    hsw_frame_shape fs;
+    const int rc = hsw_frame_query(shape, max_variable_byte_size, is_input_range_check, &fs);
+    if (rc != HSW_OK) return rc;
+    if (section != 0 && section != 1) return HSW_ERR_INVALID_ARG;
+    std::vector<uint8_t> lens;
+    if (section == 0) {
+        // lib.rs:124-165: lw, lw, mul, add, sub, is_less_than (7), its range_check (4), is_zero (8), lw, sub, 8 x lw
+        static const uint8_t fixed[] = {1, 1, 4, 4, 4, 7, 4, 8, 1, 4, 1, 1, 1, 1, 1, 1, 1, 1};
+        lens.assign(fixed, fixed + sizeof fixed);
+        lens.insert(lens.end(), max_variable_byte_size, 1);                          // :170-173
+        if (is_input_range_check) lens.insert(lens.end(), max_variable_byte_size, 4);   // :174-178
+    } else {
+        for (uint64_t n = 0; n <= fs.n_blocks; n++) {                                // :296-310
+            lens.push_back(4); lens.push_back(8);                                    // is_equal = sub row + is_zero
+            lens.insert(lens.end(), 8, 8);                                           // 8 x select
+        }
+        for (int w = 0; w < 8; w++) {                                                // :311-341
+            for (int i = 0; i < 4; i++) { lens.push_back(1); lens.push_back(4); }    // load_witness + range_check 8
+            lens.insert(lens.end(), 4, 4);                                           // 4 x mul_add
+        }
+    }
+    if (n_calls) *n_calls = lens.size();
+    if (lens_out) {
+        if (cap < lens.size()) return HSW_ERR_INVALID_ARG;
+        std::memcpy(lens_out, lens.data(), lens.size());
+    }
+    return HSW_OK;
+}
+
+// k^-1 mod p for k < n, both representations, on the device (k = 0 -> 0, never read)
+static int ensure_inv_table(hsw_engine *e, size_t n) {
+    if (n <= e->inv_n) return HSW_OK;
+    size_t cap = e->inv_n ? e->inv_n : 64;
+    while (cap < n) cap *= 2;
+    std::vector<uint64_t> canon(4 * cap, 0), mont(4 * cap, 0);
+    for (size_t k = 1; k < cap; k++) {
+        const hsw::fr::Fe im = hsw::fr::inv_mont((uint64_t)k);
+        const hsw::fr::Fe ic = hsw::fr::from_mont(im);
+        std::memcpy(&mont[4 * k], im.l, 32);
+        std::memcpy(&canon[4 * k], ic.l, 32);
+    }
+    uint64_t *d[2] = {nullptr, nullptr};
+    hipError_t he = hipMalloc((void **)&d[0], cap * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&d[1], cap * 32);
+    if (he == hipSuccess) he = hipMemcpy(d[0], canon.data(), cap * 32, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d[1], mont.data(), cap * 32, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        if (d[0]) (void)hipFree(d[0]);
+        if (d[1]) (void)hipFree(d[1]);
+        return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "inverse table", he);
+    }
+    // earlier launches may still read the old table: drain the stream before freeing it
+    if (e->d_inv_tbl[0]) { (void)hipStreamSynchronize(e->stream); (void)hipFree(e->d_inv_tbl[0]); (void)hipFree(e->d_inv_tbl[1]); }
+    e->d_inv_tbl[0] = d[0];
+    e->d_inv_tbl[1] = d[1];
+    e->inv_n = cap;
+    return HSW_OK;
+}
+
+int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                       const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
+                       void *d_lookup, uint32_t flags) {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (n == 0) return HSW_OK;
+    if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate)
+        return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    if (e->mode != HSW_MODE_HALO2_INTERNALS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
+    if (flags & ~HSW_REPR_MASK) return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
+    if (flags & HSW_REPR_COMPACT64)
+        return set_err(e, HSW_ERR_UNSUPPORTED, "digest frames hold full-width cells: no HSW_REPR_COMPACT64");
+    if (((uintptr_t)d_gate & 15u) || ((uintptr_t)d_lookup & 15u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
+    size_t max_blocks = 0;
+    e->h_frame_descs.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const hsw_frame_desc &d = descs[i];
+        if (d.n_blocks == 0) return set_err(e, HSW_ERR_UNSUPPORTED, "a digest frame needs max_variable_byte_size >= 64");
+        if ((uint64_t)d.num_round != (d.input_len + 9 + 63) / 64)
+            return set_err(e, HSW_ERR_INVALID_ARG, "num_round is not ceil((input_len + 9) / 64) (lib.rs:80-84)");
+        if (d.precomputed_round > d.num_round || d.num_round - d.precomputed_round > d.n_blocks)
+            return set_err(e, HSW_ERR_TOO_LARGE, "padded message does not fit max_variable_byte_size (lib.rs:90)");
+        hsw::FrameDesc &o = e->h_frame_descs[i];
+        o.input_len = d.input_len; o.first_block = d.first_block;
+        o.prologue_cell = d.prologue_cell; o.epilogue_cell = d.epilogue_cell;
+        o.prologue_lookup = d.prologue_lookup; o.epilogue_lookup = d.epilogue_lookup;
+        o.zero_cell = d.zero_cell; o.n_blocks = d.n_blocks; o.num_round = d.num_round;
+        o.precomputed_round = d.precomputed_round; o.range_check_inputs = d.is_input_range_check ? 1u : 0u;
+        if (d.n_blocks > max_blocks) max_blocks = d.n_blocks;
+    }
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    int rc = ensure_inv_table(e, max_blocks + 1);
+    if (rc != HSW_OK) return rc;
+    hipError_t he;
+    if (e->frame_desc_cap < n) {
+        // the previous staging buffer may still be read by an earlier launch
+        if (e->d_frame_descs) { (void)hipStreamSynchronize(e->stream); (void)hipFree(e->d_frame_descs); e->d_frame_descs = nullptr; }
+        e->frame_desc_cap = 0;
+        he = hipMalloc((void **)&e->d_frame_descs, n * sizeof(hsw::FrameDesc));
+        if (he != hipSuccess) return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "hipMalloc", he);
+        e->frame_desc_cap = n;
+    } else {
+        // one staging buffer per engine: wait until the previous frame launch has consumed it
+        he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipStreamSynchronize", he);
+    }
+    he = hipMemcpyAsync(e->d_frame_descs, e->h_frame_descs.data(), n * sizeof(hsw::FrameDesc), hipMemcpyHostToDevice,
+                        e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipMemcpyAsync", he);
+    const bool mont = (flags & HSW_REPR_MONTGOMERY) != 0;
+    he = hsw::launch_frames(e->d_frame_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
+                            d_gate, d_lookup, mont, e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_frame_kernel", he);
     return HSW_OK;
 }
 

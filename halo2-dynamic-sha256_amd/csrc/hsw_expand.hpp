@@ -846,7 +846,9 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     em.row = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 1);   // lanes >= R never flush: scratch row
     em.d16 = s_d16;
     {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
-        const u64 first = (u64)blk * (u64)LY::GATE_CELLS;
+        u64 first = (u64)blk * (u64)LY::GATE_CELLS;
+        if constexpr (RC)          // whole-digest streams: every frame_every blocks a digest frame sits in between
+            if (p.frame_every) first += (u64)(blk / p.frame_every) * p.frame_cells;
         u64 gap0 = 0;
         em.brk1 = em.brk2 = 0xffffffffu;
         em.gap1 = em.gap2 = 0;
@@ -863,7 +865,9 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         else
             em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)(first + gap0) * 2u;
     }
-    const size_t lk_blk = (size_t)blk * (size_t)LY::LOOKUP_CELLS;
+    size_t lk_blk = (size_t)blk * (size_t)LY::LOOKUP_CELLS;
+    if constexpr (RC)
+        if (p.frame_every) lk_blk += (size_t)(blk / p.frame_every) * (size_t)p.frame_lookups;
     em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
     const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
 

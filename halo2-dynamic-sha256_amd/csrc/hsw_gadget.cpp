@@ -129,10 +129,10 @@ std::vector<std::pair<uint64_t, uint64_t>> Sha256DynamicConfig::load() const {
 Context::~Context() {
     (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
-    (void)hipFree(d_init_states);
+    (void)hipFree(d_init_states); (void)hipFree(d_lookup);
 }
 
-int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out) const {
+int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
     if (!engine || !out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
@@ -150,7 +150,26 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out) const {
     c->chip_col_stride = (size_t)hsw_chip_rows(&s, 0, total);
     c->init_capacity = max_variable_byte_sizes.size();
     const size_t nb = total ? total : 1, nh = c->init_capacity ? c->init_capacity : 1;
-    hipError_t he = hipMalloc(&c->d_gate, nb * (size_t)s.gate_cells_per_block * HSW_CELL_BYTES);
+    size_t gate_cells = nb * (size_t)s.gate_cells_per_block;
+    if (whole_digest) {
+        if (s.mode != HSW_MODE_HALO2_INTERNALS) { delete c; return HSW_ERR_INVALID_ARG; }
+        c->whole = true;
+        uint64_t cells = 1, lookups = 0;                      // 1: the Context's zero cell
+        for (size_t b : max_variable_byte_sizes) {
+            hsw_frame_shape fs;
+            rc = hsw_frame_query(&s, b, is_input_range_check ? 1 : 0, &fs);
+            if (rc == HSW_OK && fs.n_blocks == 0) rc = HSW_ERR_UNSUPPORTED;
+            if (rc != HSW_OK) { delete c; return rc; }
+            cells += fs.digest_cells;
+            lookups += fs.digest_lookups;
+        }
+        c->gate_capacity = cells;
+        c->lookup_capacity = lookups;
+        gate_cells = (size_t)cells;
+    }
+    hipError_t he = hipMalloc(&c->d_gate, gate_cells * HSW_CELL_BYTES);
+    if (he == hipSuccess && whole_digest)
+        he = hipMalloc(&c->d_lookup, (size_t)(c->lookup_capacity ? c->lookup_capacity : 1) * HSW_CELL_BYTES);
     const size_t col_bytes = (size_t)s.num_advice_columns * (c->chip_col_stride ? c->chip_col_stride : 1) * HSW_CELL_BYTES;
     if (he == hipSuccess) he = hipMalloc(&c->d_chip_dense, col_bytes);
     if (he == hipSuccess) he = hipMalloc(&c->d_chip_spread, col_bytes);
@@ -239,6 +258,8 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     std::vector<uint32_t> h_next(batch_blocks * 8 ? batch_blocks * 8 : 1);
     hipError_t he = hipSuccess;
     int rc = HSW_OK;
+    std::vector<hsw_frame_desc> frames;
+    uint64_t new_gate_cursor = ctx.gate_cursor, new_lookup_cursor = ctx.lookup_cursor;
     do {
         if (batch_blocks == 0) break;
         if ((he = hipMemcpyAsync(d_blk, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
@@ -251,15 +272,81 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
             if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
         }
         const size_t G = ctx.shape.gate_cells_per_block;
-        // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
-        // Column buffers are addressed from absolute row 0 (cursor origin of the context).
-        const uint64_t row_shift = ctx.num_limb_sum / ctx.shape.num_advice_columns;
         const size_t cb = hsw_cell_bytes(ctx.repr_flags);
-        rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
-                                static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb,
-                                static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb,
-                                static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb,
-                                ctx.chip_col_stride, d_next, ctx.repr_flags);
+        const uint32_t ncols = ctx.shape.num_advice_columns;
+        if (!ctx.whole) {
+            // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
+            // Column buffers are addressed from absolute row 0 (cursor origin of the context).
+            const uint64_t row_shift = ctx.num_limb_sum / ncols;
+            rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
+                                    static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb,
+                                    static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb,
+                                    static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb,
+                                    ctx.chip_col_stride, d_next, ctx.repr_flags);
+        } else {
+            // whole-digest stream: prologue | [zero cell] | blocks | epilogue per digest (hsw_frame.hpp).
+            // Consecutive digests of equal size are ONE expansion launch (the kernel skips the frame
+            // between their block streams); all frames of the batch are one hsw_frame_kernel launch.
+            const size_t LK = ctx.shape.lookup_cells_per_block;
+            uint64_t gc = ctx.gate_cursor, lc = ctx.lookup_cursor;
+            bool zero_loaded = ctx.zero_loaded;
+            frames.resize(n);
+            std::vector<hsw_frame_shape> fss(n);
+            size_t ob = 0;
+            for (size_t i = 0; i < n && rc == HSW_OK; i++) {
+                rc = hsw_frame_query(&ctx.shape, max_variable_byte_sizes[cur_hash_idx + i], is_input_range_check ? 1 : 0, &fss[i]);
+                if (rc != HSW_OK) break;
+                hsw_frame_desc &d = frames[i];
+                AssignedHashResult &r = results[i];
+                d.input_len = input_lens[i];
+                d.first_block = b0 + ob;
+                d.n_blocks = (uint32_t)plans[i].max_variable_round;
+                d.num_round = (uint32_t)plans[i].num_round;
+                d.precomputed_round = (uint32_t)plans[i].precomputed_round;
+                d.is_input_range_check = is_input_range_check ? 1u : 0u;
+                r.prologue_cell = d.prologue_cell = gc;      gc += fss[i].prologue_cells;
+                r.prologue_lookup = d.prologue_lookup = lc;  lc += fss[i].prologue_lookups;
+                d.zero_cell = ~0ull;
+                if (!zero_loaded) { d.zero_cell = gc++; zero_loaded = true; }   // compression.rs:34 of the first block
+                r.block_cell = gc;                           gc += (uint64_t)d.n_blocks * G;
+                r.block_lookup = lc;                         lc += (uint64_t)d.n_blocks * LK;
+                r.epilogue_cell = d.epilogue_cell = gc;      gc += fss[i].epilogue_cells;
+                r.epilogue_lookup = d.epilogue_lookup = lc;  lc += fss[i].epilogue_lookups;
+                r.end_cell = gc;
+                ob += d.n_blocks;
+            }
+            if (rc == HSW_OK && (gc > ctx.gate_capacity || lc > ctx.lookup_capacity)) rc = HSW_ERR_INVALID_ARG;
+            ob = 0;
+            for (size_t i = 0; i < n && rc == HSW_OK;) {
+                size_t j = i + 1;                            // run [i, j) of equally sized digests
+                while (j < n && frames[j].n_blocks == frames[i].n_blocks) j++;
+                const size_t nb = frames[i].n_blocks, run_blocks = nb * (j - i);
+                const uint64_t cursor = ctx.num_limb_sum + (uint64_t)ob * ctx.shape.limb_calls_per_block;
+                const uint64_t row_shift = cursor / ncols;
+                hsw_witness_args a{};
+                a.d_blocks = d_blk + 64 * ob;
+                a.d_pre_states = d_pre + 8 * ob;
+                a.n_blocks = run_blocks;
+                a.spread_cursor0 = cursor;
+                a.d_gate = static_cast<uint8_t *>(ctx.d_gate) + (size_t)results[i].block_cell * cb;
+                a.d_chip_dense = static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb;
+                a.d_chip_spread = static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb;
+                a.chip_col_stride = ctx.chip_col_stride;
+                a.d_next_states = d_next + 8 * ob;
+                a.d_lookup = static_cast<uint8_t *>(ctx.d_lookup) + (size_t)results[i].block_lookup * cb;
+                a.flags = ctx.repr_flags;
+                a.frame_every = nb;
+                a.frame_cells = fss[i].epilogue_cells + fss[i].prologue_cells;
+                a.frame_lookups = fss[i].epilogue_lookups + fss[i].prologue_lookups;
+                rc = hsw_witness_blocks_ex(ctx.engine, &a);
+                ob += run_blocks;
+                i = j;
+            }
+            if (rc == HSW_OK)
+                rc = hsw_witness_frames(ctx.engine, frames.data(), n, ctx.d_blocks, ctx.d_pre_states, ctx.d_next_states,
+                                        ctx.d_gate, ctx.d_lookup, ctx.repr_flags);
+            if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
+        }
         if (rc != HSW_OK) break;
         if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         he = hipStreamSynchronize(stream);
@@ -293,6 +380,11 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         off += pl.max_variable_round;
     }
     ctx.blocks_done += batch_blocks;
+    if (ctx.whole) {
+        ctx.gate_cursor = new_gate_cursor;
+        ctx.lookup_cursor = new_lookup_cursor;
+        ctx.zero_loaded = ctx.zero_loaded || batch_blocks != 0;
+    }
     ctx.num_limb_sum += (uint64_t)batch_blocks * ctx.shape.limb_calls_per_block;   // spread.rs:228
     cur_hash_idx += n;                                                             // lib.rs:347
     return HSW_OK;
@@ -328,7 +420,13 @@ int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precompute
 
 int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                       int is_input_range_check, hsw_gadget **out) {
+    return hsw_gadget_create_ex(e, max_variable_byte_sizes, n_hashes, is_input_range_check, 0, out);
+}
+
+int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                         int is_input_range_check, uint32_t flags, hsw_gadget **out) {
     if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
+    if (flags & ~HSW_GADGET_WHOLE_DIGEST) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
     int rc = hsw_engine_shape(e, &s);
@@ -338,7 +436,7 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
     std::vector<size_t> sizes(max_variable_byte_sizes, max_variable_byte_sizes + n_hashes);
     rc = hsw::Sha256DynamicConfig::configure(sizes, s.num_bits_lookup, s.num_advice_columns,
                                              is_input_range_check != 0, &g->cfg);
-    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx);
+    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0);
     if (rc != HSW_OK) { delete g; return rc; }
     *out = g;
     return HSW_OK;
@@ -358,6 +456,10 @@ static void fill_result(const hsw::AssignedHashResult &r, hsw_hash_result *o) {
     o->num_round = r.num_round;
     o->target_round = r.target_round;
     std::memcpy(o->output_bytes, r.output_bytes, 32);
+    o->prologue_cell = r.prologue_cell; o->block_cell = r.block_cell;
+    o->epilogue_cell = r.epilogue_cell; o->end_cell = r.end_cell;
+    o->prologue_lookup = r.prologue_lookup; o->block_lookup = r.block_lookup;
+    o->epilogue_lookup = r.epilogue_lookup;
 }
 
 int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs, const size_t *input_lens,
@@ -389,6 +491,11 @@ int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
     view->capacity_blocks = g->ctx->capacity_blocks;
     view->num_limb_sum = g->ctx->num_limb_sum;
     view->cur_hash_idx = g->cfg.cur_hash_idx;
+    view->gate_cells = g->ctx->gate_cursor;
+    view->gate_capacity = g->ctx->gate_capacity;
+    view->d_lookup = g->ctx->d_lookup;
+    view->lookup_cells = g->ctx->lookup_cursor;
+    view->lookup_capacity = g->ctx->lookup_capacity;
     return HSW_OK;
 }
 
@@ -405,6 +512,7 @@ int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t 
 
 int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) {
     if (!g || (repr & ~HSW_REPR_MASK) || repr == HSW_REPR_MASK) return HSW_ERR_INVALID_ARG;
+    if (g->ctx->whole && (repr & HSW_REPR_COMPACT64)) return HSW_ERR_UNSUPPORTED;   // frames hold full-width cells
     if (g->ctx->blocks_done != 0 && hsw_cell_bytes(repr) != hsw_cell_bytes(g->ctx->repr_flags))
         return HSW_ERR_INVALID_ARG;               // the cell size of a context's streams cannot change midway
     g->ctx->repr_flags = repr;

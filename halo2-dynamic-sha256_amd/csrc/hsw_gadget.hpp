@@ -11,10 +11,11 @@
 // lib.rs:180-238 becomes ONE hsw_witness_blocks call (HIP) for all blocks of
 // a digest -- or of a whole batch of digests.
 //
-// Out of scope here: the digest epilogue's own few dozen cells
-// (length constraints lib.rs:122-151, is_equal/select lib.rs:294-310, output
-// byte decomposition lib.rs:311-341).  Their *values* are produced
-// (AssignedHashResult), their halo2-base cell placement is not.
+// SURVEY 8 f4 -- the cells digest() itself allocates around the block loop
+// (length constraints lib.rs:122-151, inputs :162-178, is_equal/select :294-310,
+// output bytes :311-341) -- are emitted by a context created with
+// HSW_GADGET_WHOLE_DIGEST (hsw_frame.hpp / hsw_frame_kernel, assumption A4);
+// without it only their *values* are produced (AssignedHashResult).
 #ifndef HSW_GADGET_HPP
 #define HSW_GADGET_HPP
 
@@ -50,6 +51,9 @@ struct AssignedHashResult {
     size_t n_blocks = 0;                 // max_variable_byte_size / 64
     uint64_t spread_cursor0 = 0;         // SpreadConfig.num_limb_sum when this digest started
     size_t num_round = 0, target_round = 0;
+    // whole-digest contexts: where the sections of this digest start (cells)
+    uint64_t prologue_cell = 0, block_cell = 0, epilogue_cell = 0, end_cell = 0;
+    uint64_t prologue_lookup = 0, block_lookup = 0, epilogue_lookup = 0;
 };
 
 class Context;
@@ -68,7 +72,8 @@ class Sha256DynamicConfig {
                          uint32_t num_advice_columns, bool is_input_range_check, Sha256DynamicConfig *out);
 
     // lib.rs:351-360: a context sized for every hash this config will assign.
-    int new_context(hsw_engine *engine, Context **out) const;
+    // whole_digest: also lay out digest()'s own cells (HSW_GADGET_WHOLE_DIGEST)
+    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false) const;
 
     // lib.rs:71-349.  precomputed_input_len = 0 is the reference's None.
     int digest(Context &ctx, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
@@ -101,6 +106,13 @@ class Context {
     uint32_t *d_init_states = nullptr;   // one per hash in flight
     size_t init_capacity = 0;
     uint32_t repr_flags = HSW_REPR_CANONICAL;
+    // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
+    // digest, back to back) and d_lookup the lookup-advice stream next to it
+    bool whole = false;
+    bool zero_loaded = false;        // Context.zero_cell (first load_zero: compression.rs:34 of the first block)
+    uint64_t gate_cursor = 0, gate_capacity = 0;       // cells
+    void *d_lookup = nullptr;
+    uint64_t lookup_cursor = 0, lookup_capacity = 0;
 };
 
 }  // namespace hsw

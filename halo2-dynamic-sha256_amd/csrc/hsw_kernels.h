@@ -36,6 +36,10 @@ struct ExpandParams {
     uint32_t n_breaks;
     uint64_t break_cell[HSW_K_MAX_BREAKS];
     uint64_t break_gap[HSW_K_MAX_BREAKS];
+    // whole-digest streams (internals mode): after every frame_every blocks the gate stream skips
+    // frame_cells cells and the lookup stream frame_lookups cells (a digest's epilogue and the
+    // next digest's prologue, written by hsw_frame_kernel); frame_every = 0: off
+    uint64_t frame_every, frame_cells, frame_lookups;
 };
 
 // limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count
@@ -49,6 +53,12 @@ hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_
 hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
                             const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
+
+struct FrameDesc;   // hsw_frame.hpp
+// d_inv_tbl: k^-1 mod p for k = 0..(largest n_blocks), 4 x u64 each, in the output representation
+hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
+                         const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
+                         bool montgomery, hipStream_t stream);
 
 }  // namespace hsw
 #endif

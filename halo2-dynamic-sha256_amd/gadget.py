@@ -18,19 +18,27 @@ class AssignedHashResult:
         self.spread_cursor0 = int(r.spread_cursor0)
         self.num_round = int(r.num_round)
         self.target_round = int(r.target_round)
+        # whole-digest contexts: where the sections of this digest start (cells), else 0
+        for k in ("prologue_cell", "block_cell", "epilogue_cell", "end_cell",
+                  "prologue_lookup", "block_lookup", "epilogue_lookup"):
+            setattr(self, k, int(getattr(r, k)))
 
 
 class Sha256DynamicConfig:
     """configure (lib.rs:49-69) + new_context (lib.rs:351-360) in one object."""
 
-    def __init__(self, engine, max_variable_byte_sizes, is_input_range_check=True):
+    def __init__(self, engine, max_variable_byte_sizes, is_input_range_check=True, whole_digest=False):
+        """whole_digest: also emit the cells digest() itself allocates (lib.rs:122-178, 294-341;
+        SURVEY 8 f4, assumption A4) -- needs an engine in HSW_MODE_HALO2_INTERNALS."""
         self.engine = engine
+        self.whole_digest = bool(whole_digest)
         self.lib = engine.lib
         self.max_variable_byte_sizes = list(max_variable_byte_sizes)
         arr = (C.c_size_t * max(len(self.max_variable_byte_sizes), 1))(*self.max_variable_byte_sizes)
         h = C.c_void_p()
-        rc = self.lib.hsw_gadget_create(engine.h, arr, len(self.max_variable_byte_sizes),
-                                        1 if is_input_range_check else 0, C.byref(h))
+        rc = self.lib.hsw_gadget_create_ex(engine.h, arr, len(self.max_variable_byte_sizes),
+                                           1 if is_input_range_check else 0,
+                                           N.HSW_GADGET_WHOLE_DIGEST if whole_digest else 0, C.byref(h))
         if rc != N.HSW_OK:
             raise N.HswError(rc, self.lib.hsw_last_error(engine.h).decode())
         self.h = h
@@ -97,7 +105,10 @@ class Sha256DynamicConfig:
             return a
 
         rows = (int(v.num_limb_sum) + ncols - 1) // ncols
-        gate = grab(v.d_gate, int(v.blocks_done) * G)
+        gate = grab(v.d_gate, int(v.gate_cells) if self.whole_digest else int(v.blocks_done) * G)
         dense = np.stack([grab(v.d_chip_dense + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
         spread = np.stack([grab(v.d_chip_spread + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
-        return dict(gate=gate, dense=dense, spread=spread, rows=rows)
+        out = dict(gate=gate, dense=dense, spread=spread, rows=rows)
+        if self.whole_digest:
+            out["lookup"] = grab(v.d_lookup, int(v.lookup_cells))
+        return out

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define HSW_ABI_VERSION 1
+#define HSW_ABI_VERSION 2
 
 /* ---- status codes ---- */
 #define HSW_OK                 0
@@ -213,6 +213,11 @@ typedef struct hsw_witness_args {
     void *d_lookup;                /* n_blocks * lookup_cells_per_block cells (HSW_MODE_HALO2_INTERNALS), or NULL */
     uint32_t flags;                /* HSW_REPR_* | HSW_SKIP_* */
     const hsw_pack_plan *pack;     /* NULL = plain linear stream */
+    /* Whole-digest streams (HSW_MODE_HALO2_INTERNALS; see "digest frame" below): the blocks are
+     * those of consecutive digests of frame_every blocks each, and between the block streams of two
+     * digests the gate stream skips frame_cells cells and the lookup stream frame_lookups cells (one
+     * digest's epilogue + the next one's prologue, written by hsw_witness_frames).  0 = off. */
+    uint64_t frame_every, frame_cells, frame_lookups;
 } hsw_witness_args;
 int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args);
 
@@ -274,6 +279,62 @@ int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precompute
                        size_t max_variable_byte_size, uint8_t *blocks_out,
                        uint32_t init_state_out[8], hsw_digest_info *info);
 
+/* ------------------------------------------------------------------------
+ * Digest frame: the cells Sha256DynamicConfig::digest itself
+ * allocates around its block loop -- the prologue (lib.rs:122-178: lengths,
+ * is_less_than_safe, the initial state, the input bytes and their optional
+ * 8-bit range checks) and the epilogue (lib.rs:294-341: is_equal/select of the
+ * state after round #target, the 32 digest bytes with their range checks and
+ * recomposition).  With them the gate stream of one digest() call is, in order,
+ *     prologue | [the Context's zero cell, at its first use] | n_blocks x G | epilogue
+ * and the lookup-advice stream  prologue_lookups | n_blocks x 3,184 | 64.
+ * Cell layout of the halo2-base calls involved (mul, sub, is_zero, is_equal,
+ * select, is_less_than, range_check(.,8), the first load_zero) follows
+ * halo2-lib v0.2.x: ASSUMPTION A4 (csrc/hsw_frame.hpp), unpinned
+ * like A1-A3.  Needs an engine in HSW_MODE_HALO2_INTERNALS; canonical or
+ * Montgomery cells (a frame has full-width cells, so no COMPACT64).
+ * ------------------------------------------------------------------------ */
+typedef struct hsw_frame_shape {
+    uint64_t n_blocks;            /* max_variable_byte_size / 64 */
+    uint64_t prologue_cells;      /* 46 + max (+ 4*max with is_input_range_check) */
+    uint64_t epilogue_cells;      /* 76*(n_blocks + 1) + 288 */
+    uint64_t prologue_lookups;    /* 3 (+ 2*max) */
+    uint64_t epilogue_lookups;    /* 64 */
+    uint64_t prologue_calls;      /* assign_region calls (tape entries) */
+    uint64_t epilogue_calls;
+    uint64_t digest_cells;        /* prologue + n_blocks*G + epilogue; the zero cell is not counted */
+    uint64_t digest_lookups;
+} hsw_frame_shape;
+int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                    hsw_frame_shape *out);
+/* The assign_region call lengths of the prologue (section 0) or epilogue
+ * (section 1), like hsw_gate_tape.  lens_out may be NULL to query the count. */
+int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                   int section, uint8_t *lens_out, size_t cap, size_t *n_calls);
+
+typedef struct hsw_frame_desc {   /* one digest() call */
+    uint64_t input_len;           /* lib.rs:77 */
+    uint64_t first_block;         /* this digest's first block in d_blocks / d_pre_states / d_next_states */
+    uint64_t prologue_cell;       /* gate-stream cell index where its prologue starts */
+    uint64_t epilogue_cell;
+    uint64_t prologue_lookup;     /* lookup-stream cell indices */
+    uint64_t epilogue_lookup;
+    uint64_t zero_cell;           /* gate-stream index of the Context's zero cell if this digest is the
+                                     first to call load_zero in its Context, else UINT64_MAX */
+    uint32_t n_blocks;            /* >= 1 */
+    uint32_t num_round;           /* ceil((input_len + 9) / 64), lib.rs:80-84 (checked) */
+    uint32_t precomputed_round;   /* lib.rs:93; num_round - precomputed_round <= n_blocks (lib.rs:90) */
+    uint32_t is_input_range_check;
+} hsw_frame_desc;
+/* Writes the frames of n digests.  d_pre_states / d_next_states are the ones the
+ * block expansion read / wrote (the candidate states of lib.rs:296 are
+ * pre_states[first_block] and next_states[first_block .. first_block+n_blocks-1]);
+ * descs is HOST memory.  d_lookup may be NULL.  Asynchronous on the engine's
+ * stream, ordered after earlier hsw_witness_blocks calls. */
+int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                       const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
+                       void *d_lookup, uint32_t flags);
+
 typedef struct hsw_gadget hsw_gadget;   /* Sha256DynamicConfig + its Context */
 
 typedef struct hsw_hash_result {        /* AssignedHashResult (lib.rs:31-36) on values */
@@ -283,6 +344,10 @@ typedef struct hsw_hash_result {        /* AssignedHashResult (lib.rs:31-36) on 
     uint64_t spread_cursor0;            /* SpreadConfig.num_limb_sum when this digest began */
     size_t num_round, target_round;
     uint8_t output_bytes[32];           /* lib.rs:311-341 */
+    /* HSW_GADGET_WHOLE_DIGEST only (else 0): where this digest's sections start in the
+     * gadget's gate / lookup streams, in cells */
+    uint64_t prologue_cell, block_cell, epilogue_cell, end_cell;
+    uint64_t prologue_lookup, block_lookup, epilogue_lookup;
 } hsw_hash_result;
 
 typedef struct hsw_gadget_view {
@@ -293,12 +358,23 @@ typedef struct hsw_gadget_view {
     size_t blocks_done, capacity_blocks;
     uint64_t num_limb_sum;              /* spread.rs:26 */
     size_t cur_hash_idx;                /* lib.rs:43 */
+    /* HSW_GADGET_WHOLE_DIGEST: d_gate is ONE stream of gate_cells cells (of gate_capacity), the
+     * digests back to back with their frames; d_lookup the lookup-advice stream.  Else 0 / NULL. */
+    uint64_t gate_cells, gate_capacity;
+    void *d_lookup;
+    uint64_t lookup_cells, lookup_capacity;
 } hsw_gadget_view;
 
 /* Sha256DynamicConfig::configure (lib.rs:49-69) + new_context (lib.rs:351-360):
  * allocates HBM for sum(max_variable_byte_sizes)/64 blocks of streams. */
 int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                       int is_input_range_check, hsw_gadget **out);
+/* flags: HSW_GADGET_WHOLE_DIGEST = also emit the digest frames (engine must be in
+ * HSW_MODE_HALO2_INTERNALS): the gadget's gate stream is then every advice cell the
+ * reference's digest() calls allocate, in allocation order. */
+#define HSW_GADGET_WHOLE_DIGEST 1u
+int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                         int is_input_range_check, uint32_t flags, hsw_gadget **out);
 void hsw_gadget_destroy(hsw_gadget *g);
 /* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.
  * Synchronous: returns once the streams of this hash are in HBM. */

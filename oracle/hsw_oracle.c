@@ -92,6 +92,20 @@ static ofe_t fe_mul(const ofe_t *a, const ofe_t *b) {
     }
     return fe_mul_slow(a, b);
 }
+static ofe_t fe_sub(const ofe_t *a, const ofe_t *b) {
+    ofe_t nb = fe_neg(b);
+    return fe_add(a, &nb);
+}
+/* a^(p-2): Field::invert for a != 0 (is_zero's witness, A4) */
+static ofe_t fe_inv(const ofe_t *a) {
+    ofe_t e = FR_P; e.l[0] -= 2;           /* p - 2, no borrow */
+    ofe_t r = fe_u64(1), base = *a;
+    for (int bit = 0; bit < 254; bit++) {
+        if ((e.l[bit / 64] >> (bit % 64)) & 1) r = fe_mul(&r, &base);
+        base = fe_mul(&base, &base);
+    }
+    return r;
+}
 /* halo2-base ScalarField::get_lower_32 / get_lower_64: low bits of the
  * canonical representation (call sites compression.rs:224,228,274,278,814,818). */
 static inline uint32_t fe_lower_32(const ofe_t *a) { return (uint32_t)a->l[0]; }
@@ -114,6 +128,12 @@ struct oracle_ctx {
     int failed; char msg[256];
     size_t block_start;            /* gate_len at the start of the current block */
     oracle_constraints_t *rec;     /* constraint-structure recorder (next block only), or NULL */
+    /* whole-digest mode (oracle_digest_cells): cell ids are absolute stream indices, the
+     * Context's zero cell is a stream cell, and the recorder stays attached across blocks */
+    int whole;
+    int zero_loaded; int64_t zero_cell;       /* Context.zero_cell (A4-iii) */
+    uint8_t *call_lens; size_t call_cap, n_calls;     /* assign_region call lengths, in order */
+    uint64_t *gate_rows; size_t rows_cap, n_rows;     /* stream index of every enabled gate row */
 };
 
 static void ofail(oracle_ctx *c, const char *what, uint64_t a, uint64_t b) {
@@ -195,6 +215,25 @@ static void rec_range(oracle_ctx *c, int64_t cell_id, int bits) {
     r->n_range++;
 }
 
+/* One FlexGateConfig::assign_region call of `len` cells starting at the current
+ * stream position, with the gate selector enabled at the given offsets
+ * (halo2-base `gate_offsets`; -1 = unused).  Feeds the call-length tape and the
+ * list of gate rows when they are attached. */
+static void region(oracle_ctx *c, int len, int g0, int g1) {
+    if (c->call_lens && c->n_calls < c->call_cap) c->call_lens[c->n_calls] = (uint8_t)len;
+    c->n_calls++;
+    const int g[2] = {g0, g1};
+    for (int i = 0; i < 2; i++) {
+        if (g[i] < 0) continue;
+        if (c->gate_rows && c->n_rows < c->rows_cap) c->gate_rows[c->n_rows] = (uint64_t)c->gate_len + (uint64_t)g[i];
+        c->n_rows++;
+    }
+}
+static void region_row(oracle_ctx *c, size_t at) {      /* a further gate row of the region just opened */
+    if (c->gate_rows && c->n_rows < c->rows_cap) c->gate_rows[c->n_rows] = (uint64_t)at;
+    c->n_rows++;
+}
+
 /* One advice cell of the gate stream holding QuantumCell q.  Existing(x): the new
  * cell is copy-constrained to x's cell; Constant(k): fixed to k; Witness: free.
  * Returns the new cell's block-relative index. */
@@ -209,8 +248,10 @@ static inline int64_t cell(oracle_ctx *c, const av_t *q, int is_witness) {
     c->gate_len++;
     c->st.gate_cells++;
     if (!is_witness) {
-        if (q->cell == CELL_CONST) rec_const(c, idx, q->v.l[0]);
-        else rec_eq(c, idx, q->cell);
+        if (q->cell == CELL_CONST) {
+            if (fe_is_u64(&q->v)) rec_const(c, idx, q->v.l[0]);
+            else { ofe_t m = fe_neg(&q->v); rec_const(c, idx, (uint64_t)(-(int64_t)m.l[0])); }   /* p - k, k small: stored as -k */
+        } else rec_eq(c, idx, q->cell);
     }
     return idx;
 }
@@ -223,16 +264,31 @@ static inline av_t witness_cell(oracle_ctx *c, ofe_t v) {
 static av_t g_load_witness(oracle_ctx *c, ofe_t v) {
     c->st.load_witness++;
     c->cur_kind = 0;
+    region(c, 1, -1, -1);
     return witness_cell(c, v);
 }
 /* GateInstructions::load_zero: cached in the Context (assumption A2): one cell
  * outside the stream, fixed to 0. */
-static av_t g_load_zero(oracle_ctx *c) { c->st.load_zero++; return ext_cell(0, ORACLE_CELL_ZERO); }
+static av_t g_load_zero(oracle_ctx *c) {
+    c->st.load_zero++;
+    if (!c->whole) return ext_cell(0, ORACLE_CELL_ZERO);
+    /* whole-digest mode, ASSUMPTION A4-iii (halo2-lib v0.2.x load_zero): the first call in a
+     * Context assigns [Constant(0)] as a one-cell region and caches it in ctx.zero_cell */
+    if (!c->zero_loaded) {
+        av_t zero = K(0);
+        c->cur_kind = 0;
+        region(c, 1, -1, -1);
+        c->zero_cell = cell(c, &zero, 0);
+        c->zero_loaded = 1;
+    }
+    return ext_cell(0, c->zero_cell);
+}
 /* GateInstructions::add -> [a, b, 1, a+b] */
 static av_t g_add(oracle_ctx *c, av_t a, av_t b) {
     c->st.add++;
     av_t one = K(1);
     c->cur_kind = 1;
+    region(c, 4, 0, -1);
     cell(c, &a, 0); cell(c, &b, 0); cell(c, &one, 0);
     return witness_cell(c, fe_add(&a.v, &b.v));
 }
@@ -241,6 +297,7 @@ static av_t g_neg(oracle_ctx *c, av_t a) {
     c->st.neg++;
     av_t one = K(1), zero = K(0);
     c->cur_kind = 1;
+    region(c, 4, 0, -1);
     cell(c, &a, 0);
     av_t out = witness_cell(c, fe_neg(&a.v));
     cell(c, &one, 0); cell(c, &zero, 0);
@@ -251,6 +308,7 @@ static av_t g_mul_add(oracle_ctx *c, av_t a, av_t b, av_t cc) {
     c->st.mul_add++;
     ofe_t ab = fe_mul(&a.v, &b.v);
     c->cur_kind = 1;
+    region(c, 4, 0, -1);
     cell(c, &cc, 0); cell(c, &a, 0); cell(c, &b, 0);
     return witness_cell(c, fe_add(&ab, &cc.v));
 }
@@ -288,7 +346,7 @@ static void r_enable_lookup(oracle_ctx *c, const av_t *v) {
  *           not reachable from this gadget).
  * The cells are emitted only with oracle_set_internals(1); the lookup queue, the
  * recorded range bound and the range self-check always run. */
-static void r_range_check(oracle_ctx *c, av_t a, int bits) {
+static void r_range_check_limbs(oracle_ctx *c, av_t a, int bits, av_t *limbs_out) {
     if (bits == 16) c->st.range_check16++;
     else if (bits == 32) c->st.range_check32++;
     else c->st.range_check_other++;
@@ -302,6 +360,7 @@ static void r_range_check(oracle_ctx *c, av_t a, int bits) {
     av_t last = a;
     if (k == 1) {
         r_enable_lookup(c, &a);
+        if (limbs_out) limbs_out[0] = a;
     } else {
         av_t limbs[8];
         for (int i = 0; i < k && i < 8; i++) {
@@ -310,6 +369,9 @@ static void r_range_check(oracle_ctx *c, av_t a, int bits) {
         }
         if (c->internals) {
             c->cur_kind = 1;                                   /* rows overlap: [s, a, b, s'] */
+            region(c, 1 + 3 * (k - 1), 0, -1);
+            const size_t at = c->gate_len;
+            for (int i = 2; i < k; i++) region_row(c, at + 3 * (size_t)(i - 1));
             limbs[0] = witness_cell(c, limbs[0].v);
             av_t sum = limbs[0];
             for (int i = 1; i < k; i++) {
@@ -324,6 +386,7 @@ static void r_range_check(oracle_ctx *c, av_t a, int bits) {
             rec_eq(c, sum.cell, a.cell);                       /* constrain_equal(a, acc) */
         }
         for (int i = 0; i < k; i++) r_enable_lookup(c, &limbs[i]);
+        if (limbs_out) for (int i = 0; i < k && i < 8; i++) limbs_out[i] = limbs[i];
         last = limbs[k - 1];
     }
     if (rem > 1) {
@@ -331,11 +394,109 @@ static void r_range_check(oracle_ctx *c, av_t a, int bits) {
         av_t out; out.v = fe_mul(&last.v, &mult.v); out.cell = ORACLE_CELL_HIDDEN;
         if (c->internals) {
             c->cur_kind = 1;
+            region(c, 4, 0, -1);
             cell(c, &zero, 0); cell(c, &last, 0); cell(c, &mult, 0);
             out = witness_cell(c, out.v);
         }
         r_enable_lookup(c, &out);
     }
+}
+static void r_range_check(oracle_ctx *c, av_t a, int bits) { r_range_check_limbs(c, a, bits, NULL); }
+
+/* ------------------------------------------- halo2-base calls of lib.rs::digest
+ * ASSUMPTION A4 (halo2-lib v0.2.x flex_gate.rs / range.rs, Vertical strategy; source
+ * absent from the reference tree, so UNPINNED like A1-A3).  Only `digest`'s own
+ * prologue / epilogue uses these (lib.rs:122-178, 294-341):
+ *   mul(a, b)          -> [0, a, b, a*b]
+ *   sub(a, b)          -> [a-b, b, 1, a]                       (returns cell 0)
+ *   is_zero(a)         -> [z, a, inv, 1, 0, a, z, 0]           gates at 0 and 4, cell 6 = cell 0;
+ *                         z = (a == 0), inv = a^-1 (1 if a == 0):  z + a*inv = 1,  0 + a*z = 0
+ *   is_equal(a, b)     -> [a-b, 1, b, a] then is_zero(cell 0)
+ *   select(a, b, sel)  -> [a-b, 1, b, a, b, sel, a-b, out]     gates at 0 and 4, cell 6 = cell 0;
+ *                         out = (a-b)*sel + b
+ *   is_less_than(a, b, n): pb = ceil(n / lookup_bits) * lookup_bits
+ *                      -> [a+2^pb-b, b, 1, a+2^pb, -2^pb, 1, a] gates at 0 and 3,
+ *                         range_check(cell 0, pb + lookup_bits), is_zero(top limb)
+ *   is_less_than_safe(a, b: u64): n = bit_length(b) rounded up to a multiple of
+ *                         lookup_bits; range_check(a, n); is_less_than(a, Constant(b), n)
+ *   assert_is_const(a, k): a's cell fixed to k, no new cell. */
+static av_t g_mul(oracle_ctx *c, av_t a, av_t b) {
+    av_t zero = K(0);
+    c->cur_kind = 1;
+    region(c, 4, 0, -1);
+    cell(c, &zero, 0); cell(c, &a, 0); cell(c, &b, 0);
+    return witness_cell(c, fe_mul(&a.v, &b.v));
+}
+static av_t g_sub(oracle_ctx *c, av_t a, av_t b) {
+    av_t one = K(1);
+    c->cur_kind = 1;
+    region(c, 4, 0, -1);
+    av_t out = witness_cell(c, fe_sub(&a.v, &b.v));
+    cell(c, &b, 0); cell(c, &one, 0); cell(c, &a, 0);
+    return out;
+}
+static av_t g_is_zero(oracle_ctx *c, av_t a) {
+    const int z = fe_is_zero(&a.v);
+    av_t one = K(1), zero = K(0);
+    c->cur_kind = 1;
+    region(c, 8, 0, 4);
+    av_t is_zero = witness_cell(c, fe_u64(z ? 1 : 0));
+    cell(c, &a, 0);
+    witness_cell(c, z ? fe_u64(1) : fe_inv(&a.v));
+    cell(c, &one, 0);
+    c->cur_kind = 1;
+    cell(c, &zero, 0); cell(c, &a, 0); cell(c, &is_zero, 0); cell(c, &zero, 0);
+    return is_zero;
+}
+static av_t g_is_equal(oracle_ctx *c, av_t a, av_t b) {
+    av_t one = K(1);
+    c->cur_kind = 1;
+    region(c, 4, 0, -1);
+    av_t diff = witness_cell(c, fe_sub(&a.v, &b.v));
+    cell(c, &one, 0); cell(c, &b, 0); cell(c, &a, 0);
+    return g_is_zero(c, diff);
+}
+static av_t g_select(oracle_ctx *c, av_t a, av_t b, av_t sel) {
+    av_t one = K(1);
+    ofe_t diff_v = fe_sub(&a.v, &b.v);
+    ofe_t prod = fe_mul(&diff_v, &sel.v);
+    c->cur_kind = 1;
+    region(c, 8, 0, 4);
+    av_t diff = witness_cell(c, diff_v);
+    cell(c, &one, 0); cell(c, &b, 0); cell(c, &a, 0);
+    c->cur_kind = 1;
+    cell(c, &b, 0); cell(c, &sel, 0); cell(c, &diff, 0);
+    return witness_cell(c, fe_add(&prod, &b.v));
+}
+static void g_assert_is_const(oracle_ctx *c, av_t a, uint64_t k) {
+    if (c->check && !(fe_is_u64(&a.v) && a.v.l[0] == k)) ofail(c, "assert_is_const violated", a.v.l[0], k);
+    rec_const(c, a.cell, k);
+}
+static av_t r_is_less_than(oracle_ctx *c, av_t a, av_t b, int num_bits) {
+    const int lb = c->lookup_bits;
+    const int k = (num_bits + lb - 1) / lb, padded_bits = k * lb;
+    ofe_t pow_padded = fe_u64(1ULL << padded_bits);
+    av_t one = K(1), neg_pow;
+    neg_pow.v = fe_neg(&pow_padded); neg_pow.cell = CELL_CONST;
+    ofe_t shift_a_val = fe_add(&a.v, &pow_padded);
+    ofe_t shifted_val = fe_sub(&shift_a_val, &b.v);
+    c->cur_kind = 1;
+    region(c, 7, 0, 3);
+    av_t shifted = witness_cell(c, shifted_val);
+    cell(c, &b, 0); cell(c, &one, 0);
+    witness_cell(c, shift_a_val);
+    c->cur_kind = 2;
+    cell(c, &neg_pow, 0); cell(c, &one, 0); cell(c, &a, 0);
+    av_t limbs[8];
+    r_range_check_limbs(c, shifted, padded_bits + lb, limbs);
+    return g_is_zero(c, limbs[k]);
+}
+static int bit_length_u64(uint64_t x) { int n = 0; while (x) { n++; x >>= 1; } return n; }
+static av_t r_is_less_than_safe(oracle_ctx *c, av_t a, uint64_t b) {
+    const int lb = c->lookup_bits;
+    const int range_bits = (bit_length_u64(b) + lb - 1) / lb * lb;
+    r_range_check(c, a, range_bits);
+    return r_is_less_than(c, a, K(b), range_bits);
 }
 
 /* -------------------------------------------------------------- utils.rs */
@@ -622,13 +783,8 @@ static av_t sigma_lower1(oracle_ctx *c, const spread_u32 *x) {
 }
 
 /* compression.rs:19-213 */
-int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
-                              const uint32_t pre_state[8], uint32_t next_state[8]) {
-    c->block_start = c->gate_len;
-    /* the caller's assigned_input_bytes / pre_state_words (lib.rs:162-173): cells outside the stream */
-    av_t assigned_input_bytes[64], pre_state_words[8];
-    for (int i = 0; i < 64; i++) assigned_input_bytes[i] = ext_cell(block[i], ORACLE_CELL_INPUT_BYTE0 - i);
-    for (int i = 0; i < 8; i++) pre_state_words[i] = ext_cell(pre_state[i], ORACLE_CELL_PRE_STATE0 - i);
+static void compression_core(oracle_ctx *c, const av_t assigned_input_bytes[64], const av_t pre_state_words[8],
+                             av_t out_words[8]) {
 
     /* message schedule: :31-47 */
     av_t message_u32s[64];
@@ -702,9 +858,21 @@ int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
     av_t new_states[8] = {a, b, cc, d, e, f, g, h};         /* :197 */
     for (int i = 0; i < 8; i++) {                           /* :198-211 */
         av_t add = g_add(c, new_states[i], pre_state_words[i]);
-        av_t out = mod_u32(c, add);
-        if (next_state) next_state[i] = fe_lower_32(&out.v);
-        if (c->rec && c->rec->next_state_cells) c->rec->next_state_cells[i] = out.cell;
+        out_words[i] = mod_u32(c, add);
+    }
+}
+
+int oracle_sha256_compression(oracle_ctx *c, const uint8_t block[64],
+                              const uint32_t pre_state[8], uint32_t next_state[8]) {
+    c->block_start = c->gate_len;
+    /* the caller's assigned_input_bytes / pre_state_words (lib.rs:162-173): cells outside the stream */
+    av_t assigned_input_bytes[64], pre_state_words[8], out[8];
+    for (int i = 0; i < 64; i++) assigned_input_bytes[i] = ext_cell(block[i], ORACLE_CELL_INPUT_BYTE0 - i);
+    for (int i = 0; i < 8; i++) pre_state_words[i] = ext_cell(pre_state[i], ORACLE_CELL_PRE_STATE0 - i);
+    compression_core(c, assigned_input_bytes, pre_state_words, out);
+    for (int i = 0; i < 8; i++) {
+        if (next_state) next_state[i] = fe_lower_32(&out[i].v);
+        if (c->rec && c->rec->next_state_cells) c->rec->next_state_cells[i] = out[i].cell;
     }
     c->rec = NULL;      /* the structure is input independent: recorded for one block only */
     return c->failed;
@@ -813,6 +981,125 @@ int oracle_digest(oracle_ctx *c, const uint8_t *input, size_t input_byte_size,
     free(padded_inputs);
     return c->failed ? 1 : 0;
 }
+
+/* lib.rs:71-349 with EVERY cell digest() itself allocates, under
+ * assumptions A1-A4: prologue (lib.rs:122-178), the Context's zero cell at its
+ * first use (compression.rs:34 of the first block of a context), the block loop
+ * (lib.rs:180-238), the epilogue (lib.rs:294-341).  Cell ids are absolute stream
+ * indices, so an attached constraint recorder sees the copy constraints between
+ * the sections (input bytes -> word packing, states -> next block / select). */
+int oracle_digest_cells(oracle_ctx *c, const uint8_t *input, size_t input_byte_size,
+                        size_t precomputed_input_len, size_t max_variable_byte_size,
+                        int is_input_range_check, uint8_t digest[32], oracle_digest_layout_t *lay) {
+    if (!c->internals) return 20;        /* the frame consists of halo2-base internals */
+    const size_t one_round_size = 64;                                       /* :48 */
+    if (max_variable_byte_size % one_round_size != 0) return 10;           /* :57-59 */
+    size_t input_byte_size_with_9 = input_byte_size + 9;                    /* :78 */
+    size_t num_round = (input_byte_size_with_9 + one_round_size - 1) / one_round_size;   /* :80-84 */
+    size_t padded_size = one_round_size * num_round;                        /* :85 */
+    size_t max_variable_round = max_variable_byte_size / one_round_size;    /* :87 */
+    if (precomputed_input_len % one_round_size != 0) return 11;             /* :89 */
+    if (precomputed_input_len > padded_size ||
+        padded_size - precomputed_input_len > max_variable_byte_size) return 12;   /* :90 */
+    size_t zero_padding_byte_size = padded_size - input_byte_size_with_9;   /* :91 */
+    size_t precomputed_round = precomputed_input_len / one_round_size;      /* :93 */
+    size_t total = max_variable_byte_size + precomputed_input_len;
+    uint8_t *padded_inputs = (uint8_t *)calloc(total ? total : 1, 1);       /* :98-117 */
+    av_t *assigned_input_bytes = (av_t *)calloc(max_variable_byte_size ? max_variable_byte_size : 1, sizeof(av_t));
+    av_t (*states)[8] = (av_t (*)[8])calloc(max_variable_round + 1, sizeof(av_t[8]));
+    if (!padded_inputs || !assigned_input_bytes || !states) { free(padded_inputs); free(assigned_input_bytes); free(states); return 14; }
+    size_t n = 0;
+    if (input_byte_size) memcpy(padded_inputs, input, input_byte_size);
+    n += input_byte_size;
+    padded_inputs[n++] = 0x80;
+    n += zero_padding_byte_size;
+    uint64_t bitlen = 8ULL * (uint64_t)input_byte_size;
+    for (int i = 7; i >= 0; i--) padded_inputs[n++] = (uint8_t)(bitlen >> (8 * i));
+
+    const int was_whole = c->whole;
+    const size_t saved_block_start = c->block_start;
+    c->whole = 1;
+    c->block_start = 0;                   /* cell ids = absolute stream indices */
+    const size_t g0 = c->gate_len, l0 = c->lookup_len;
+
+    /* ---- prologue: lib.rs:122-178 ---- */
+    av_t assigned_input_byte_size = g_load_witness(c, fe_u64(input_byte_size));                 /* :124-125 */
+    av_t assigned_num_round = g_load_witness(c, fe_u64(num_round));                             /* :126 */
+    av_t assigned_padded_size = g_mul(c, assigned_num_round, K(one_round_size));                /* :127-131 */
+    av_t assigned_input_with_9_size = g_add(c, assigned_input_byte_size, K(9));                 /* :132-136 */
+    av_t padding_size = g_sub(c, assigned_padded_size, assigned_input_with_9_size);             /* :137-141 */
+    av_t padding_is_less_than_round = r_is_less_than_safe(c, padding_size, one_round_size);     /* :142-143 */
+    g_assert_is_const(c, padding_is_less_than_round, 1);                                        /* :144 */
+    av_t assigned_precomputed_round = g_load_witness(c, fe_u64(precomputed_round));             /* :145-146 */
+    av_t assigned_target_round = g_sub(c, assigned_num_round, assigned_precomputed_round);      /* :147-151 */
+    uint32_t last_state[8];                                                                     /* :155-160 */
+    memcpy(last_state, INIT_STATE, sizeof last_state);
+    for (size_t r = 0; r < precomputed_round; r++)
+        oracle_plain_compress(last_state, padded_inputs + r * one_round_size);
+    for (int i = 0; i < 8; i++) states[0][i] = g_load_witness(c, fe_u64(last_state[i]));       /* :162-165 */
+    for (size_t i = 0; i < max_variable_byte_size; i++)                                         /* :170-173 */
+        assigned_input_bytes[i] = g_load_witness(c, fe_u64(padded_inputs[precomputed_input_len + i]));
+    if (is_input_range_check)                                                                   /* :174-178 */
+        for (size_t i = 0; i < max_variable_byte_size; i++) r_range_check(c, assigned_input_bytes[i], 8);
+    const size_t g1 = c->gate_len, l1 = c->lookup_len;
+
+    /* ---- block loop: lib.rs:180-238 (the first load_zero of a context lands here) ---- */
+    const int zero_before = c->zero_loaded;
+    size_t zero_cells = 0, g2 = g1;
+    for (size_t r = 0; r < max_variable_round; r++) {
+        if (r == 0 && !c->zero_loaded) { g_load_zero(c); zero_cells = 1; g2 = c->gate_len; c->st.load_zero--; }
+        compression_core(c, assigned_input_bytes + r * one_round_size, states[r], states[r + 1]);
+    }
+    (void)zero_before;
+    const size_t g3 = c->gate_len, l3 = c->lookup_len;
+
+    /* ---- epilogue: lib.rs:294-341 ---- */
+    av_t zero = g_load_zero(c);                                                                 /* :294 */
+    av_t output_h_out[8];
+    for (int i = 0; i < 8; i++) output_h_out[i] = zero;                                         /* :295 */
+    for (size_t n_round = 0; n_round <= max_variable_round; n_round++) {                        /* :296 */
+        av_t selector = g_is_equal(c, K(n_round), assigned_target_round);                       /* :297-301 */
+        for (int i = 0; i < 8; i++)                                                             /* :302-309 */
+            output_h_out[i] = g_select(c, states[n_round][i], output_h_out[i], selector);
+    }
+    for (int w = 0; w < 8; w++) {                                                               /* :311-341 */
+        const uint32_t word = fe_lower_32(&output_h_out[w].v);                                  /* :314-316 */
+        av_t assigned_bytes[4];
+        for (int idx = 0; idx < 4; idx++) {                                                     /* :317-324 */
+            const uint8_t be = (uint8_t)(word >> (24 - 8 * idx));
+            assigned_bytes[idx] = g_load_witness(c, fe_u64(be));
+            r_range_check(c, assigned_bytes[idx], 8);
+            digest[4 * w + idx] = be;
+        }
+        av_t sum = g_load_zero(c);                                                              /* :325 */
+        for (int idx = 0; idx < 4; idx++)                                                       /* :326-333 */
+            sum = g_mul_add(c, assigned_bytes[idx], K(1ULL << (24 - 8 * idx)), sum);
+        g_assert_equal(c, output_h_out[w], sum);                                                /* :334-338 */
+    }
+    if (lay) {
+        lay->prologue_cells = g1 - g0;
+        lay->zero_cells = zero_cells;
+        lay->block_cells = g3 - g2;
+        lay->epilogue_cells = c->gate_len - g3;
+        lay->prologue_lookups = l1 - l0;
+        lay->block_lookups = l3 - l1;
+        lay->epilogue_lookups = c->lookup_len - l3;
+        lay->num_round = num_round;
+        lay->target_round = num_round - precomputed_round;
+        lay->n_blocks = max_variable_round;
+        lay->input_len_cell = assigned_input_byte_size.cell;
+    }
+    c->whole = was_whole;
+    c->block_start = saved_block_start;
+    free(padded_inputs); free(assigned_input_bytes); free(states);
+    return c->failed ? 1 : 0;
+}
+void oracle_set_tape(oracle_ctx *c, uint8_t *call_lens, size_t call_cap, uint64_t *gate_rows, size_t rows_cap) {
+    c->call_lens = call_lens; c->call_cap = call_cap; c->n_calls = 0;
+    c->gate_rows = gate_rows; c->rows_cap = rows_cap; c->n_rows = 0;
+}
+size_t oracle_tape_calls(const oracle_ctx *c) { return c->n_calls; }
+size_t oracle_tape_rows(const oracle_ctx *c) { return c->n_rows; }
 
 /* Canonical -> Montgomery form (halo2curves bn256::Fr in-memory representation:
  * x * 2^256 mod p), by generic 512-bit multiply + bit-serial reduction --

@@ -155,6 +155,37 @@ int oracle_digest(oracle_ctx *c, const uint8_t *input, size_t input_len,
                   uint8_t digest[32], uint8_t *blocks_out,
                   uint32_t *pre_states_out, uint32_t *next_states_out);
 
+/* lib.rs:71-349 with EVERY cell digest() itself allocates appended
+ * to the gate / lookup streams: prologue (lib.rs:122-178) | the Context's zero
+ * cell, at its first use in a context | max/64 blocks | epilogue (lib.rs:294-341).
+ * Needs oracle_set_internals(1) (returns 20 otherwise): the frame is made of
+ * halo2-base calls whose cells are ASSUMPTION A4 (halo2-lib v0.2.x, unpinned):
+ *   mul(a,b) -> [0,a,b,ab]        sub(a,b) -> [a-b,b,1,a]
+ *   is_zero(a) -> [z,a,inv,1,0,a,z,0]            (rows at 0 and 4)
+ *   is_equal(a,b) -> [a-b,1,b,a] + is_zero        select(a,b,s) -> [a-b,1,b,a,b,s,a-b,out]
+ *   is_less_than(a,b,n) -> [a+2^pb-b,b,1,a+2^pb,-2^pb,1,a] (rows at 0 and 3)
+ *                          + range_check(.,pb+16) + is_zero(top limb)
+ *   range_check(a,8) -> lookup a; [0,a,2^8,a*2^8]; lookup the last cell
+ *   load_zero: first call in a Context assigns one cell [0], later calls none.
+ * With a constraint recorder attached (oracle_record_constraints) cell ids are
+ * ABSOLUTE stream indices and the recorder stays attached for the whole digest;
+ * constants that are p - k are recorded as -k. */
+typedef struct {
+    size_t prologue_cells, zero_cells, block_cells, epilogue_cells;   /* sections of the gate stream, in order */
+    size_t prologue_lookups, block_lookups, epilogue_lookups;         /* sections of the lookup stream */
+    size_t num_round, target_round, n_blocks;
+    int64_t input_len_cell;                                           /* AssignedHashResult.input_len */
+} oracle_digest_layout_t;
+int oracle_digest_cells(oracle_ctx *c, const uint8_t *input, size_t input_len,
+                        size_t precomputed_input_len, size_t max_variable_byte_size,
+                        int is_input_range_check, uint8_t digest[32], oracle_digest_layout_t *lay);
+/* Optional recorders of the halo2-base call structure: the length of every
+ * assign_region call (the replay tape) and the stream index of every enabled
+ * gate row (x0 + x1*x2 = x3 on cells [i, i+3]).  Reset by this call. */
+void oracle_set_tape(oracle_ctx *c, uint8_t *call_lens, size_t call_cap, uint64_t *gate_rows, size_t rows_cap);
+size_t oracle_tape_calls(const oracle_ctx *c);
+size_t oracle_tape_rows(const oracle_ctx *c);
+
 /* Plain SHA-256 compression (FIPS 180-4; what sha2::compress256 computes). */
 void oracle_plain_compress(uint32_t state[8], const uint8_t block[64]);
 

@@ -59,6 +59,17 @@ def build(force=False):
     return _LIB_PATH
 
 
+class DigestLayout(C.Structure):
+    """oracle_digest_layout_t"""
+    _fields_ = [(n, C.c_size_t) for n in (
+        "prologue_cells", "zero_cells", "block_cells", "epilogue_cells",
+        "prologue_lookups", "block_lookups", "epilogue_lookups",
+        "num_round", "target_round", "n_blocks")] + [("input_len_cell", C.c_int64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 _lib = None
 
 
@@ -93,6 +104,14 @@ def lib():
         L.oracle_digest.restype = C.c_int
         L.oracle_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_digest_cells.restype = C.c_int
+        L.oracle_digest_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                          C.c_void_p, C.POINTER(DigestLayout)]
+        L.oracle_set_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle_tape_calls.restype = C.c_size_t
+        L.oracle_tape_calls.argtypes = [C.c_void_p]
+        L.oracle_tape_rows.restype = C.c_size_t
+        L.oracle_tape_rows.argtypes = [C.c_void_p]
         L.oracle_plain_compress.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_spread_table_entry.restype = C.c_uint64
         L.oracle_spread_table_entry.argtypes = [C.c_uint32]
@@ -240,6 +259,78 @@ class Oracle:
         out.update(digest=dig.tobytes(), blocks=blocks[:nblk], pre_states=pre[:nblk],
                    next_states=nxt[:nblk])
         return out
+
+
+def digest_cells(messages, max_sizes, precomputed=None, is_input_range_check=False, record=False,
+                 num_bits_lookup=8, num_advice_columns=2):
+    """len(messages) consecutive Sha256DynamicConfig::digest calls in ONE fresh Context
+    (the reference's TestCircuit makes two, lib.rs:455-466) with every cell digest()
+    allocates, under assumptions A1-A4 (hsw_oracle.h: oracle_digest_cells).
+    Returns dict: gate (N,4) u64, lookup (M,4) u64, dense/spread (ncols, rows, 4), digests,
+    layouts (one dict per digest, plus gate0/lookup0 = where its sections start),
+    call_lens (u8, the assign_region tape), gate_rows (stream index of every gate row) and,
+    with record=True, cs = the constraint structure on absolute cell ids."""
+    precomputed = precomputed or [0] * len(messages)
+    G, LC = measure_shape(num_bits_lookup, num_advice_columns, True)
+    LK = lookup_cells_per_block(num_bits_lookup, num_advice_columns)
+    nblk = [m // 64 for m in max_sizes]
+    rc = 4 if is_input_range_check else 0
+    gcap = sum(64 + (1 + rc) * m + b * G + 76 * (b + 1) + 288 for m, b in zip(max_sizes, nblk))
+    lcap = sum(8 + 2 * m + b * LK + 64 for m, b in zip(max_sizes, nblk))
+    tot_blk = sum(nblk)
+    rows = (LC * tot_blk + num_advice_columns - 1) // num_advice_columns
+    o = Oracle(num_bits_lookup, num_advice_columns, check=True, internals=True)
+    gate = np.zeros((gcap, 4), dtype=np.uint64)
+    lookup = np.zeros((lcap, 4), dtype=np.uint64)
+    dense = np.zeros((num_advice_columns, max(rows, 1), 4), dtype=np.uint64)
+    spread = np.zeros((num_advice_columns, max(rows, 1), 4), dtype=np.uint64)
+    call_lens = np.zeros(gcap, dtype=np.uint8)
+    gate_rows = np.zeros(gcap, dtype=np.uint64)
+    L = o.L
+    L.oracle_set_outputs(o.h, gate.ctypes.data, gcap, dense.ctypes.data, spread.ctypes.data, dense.shape[1], 0)
+    L.oracle_set_lookup_output(o.h, lookup.ctypes.data, lcap)
+    L.oracle_set_tape(o.h, call_lens.ctypes.data, gcap, gate_rows.ctypes.data, gcap)
+    cs = None
+    if record:
+        cap = gcap
+        eq = np.zeros((cap, 2), dtype=np.int64)
+        konst = np.zeros((cap, 2), dtype=np.int64)
+        rng_ = np.zeros((cap, 2), dtype=np.int64)
+        chip = np.zeros((LC * tot_blk, 2), dtype=np.int64)
+        lk = np.zeros(lcap, dtype=np.int64)
+        nsc = np.zeros(8, dtype=np.int64)
+        cst = _Constraints(eq.ctypes.data, cap, 0, konst.ctypes.data, cap, 0, rng_.ctypes.data, cap, 0,
+                           chip.ctypes.data, LC * tot_blk, 0, lk.ctypes.data, lcap, 0, nsc.ctypes.data)
+        L.oracle_record_constraints(o.h, C.byref(cst))
+    digests, layouts = [], []
+    for msg, mx, pre in zip(messages, max_sizes, precomputed):
+        m = np.frombuffer(bytes(msg), dtype=np.uint8).copy()
+        dig = np.zeros(32, dtype=np.uint8)
+        lay = DigestLayout()
+        g0, l0 = int(L.oracle_gate_len(o.h)), int(L.oracle_lookup_len(o.h))
+        r = L.oracle_digest_cells(o.h, m.ctypes.data if len(m) else None, len(m), pre, mx,
+                                  1 if is_input_range_check else 0, dig.ctypes.data, C.byref(lay))
+        if r >= 10:
+            raise ValueError("reference assert would fire (oracle_digest_cells rc=%d)" % r)
+        o._check()
+        d = lay.as_dict()
+        d.update(gate0=g0, lookup0=l0)
+        layouts.append(d)
+        digests.append(dig.tobytes())
+    n_gate, n_lk = int(L.oracle_gate_len(o.h)), int(L.oracle_lookup_len(o.h))
+    n_calls, n_rows = int(L.oracle_tape_calls(o.h)), int(L.oracle_tape_rows(o.h))
+    assert n_gate <= gcap and n_lk <= lcap and n_calls <= gcap and n_rows <= gcap
+    if record:
+        L.oracle_record_constraints(o.h, None)
+        assert cst.n_eq <= cap and cst.n_const <= cap and cst.n_range <= cap
+        cs = dict(eq=eq[:cst.n_eq].copy(), const=konst[:cst.n_const].copy(), range=rng_[:cst.n_range].copy(),
+                  chip=chip[:cst.n_chip].copy(), lookup_src=lk[:cst.n_lookup].copy())
+    L.oracle_set_tape(o.h, None, 0, None, 0)
+    L.oracle_set_lookup_output(o.h, None, 0)
+    L.oracle_set_outputs(o.h, None, 0, None, None, 0, 0)
+    return dict(gate=gate[:n_gate].copy(), lookup=lookup[:n_lk].copy(), dense=dense, spread=spread,
+                digests=digests, layouts=layouts, call_lens=call_lens[:n_calls].copy(),
+                gate_rows=gate_rows[:n_rows].astype(np.int64), cs=cs, G=G, LC=LC, LK=LK)
 
 
 CELL_ZERO = -1000

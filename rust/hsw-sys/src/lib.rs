@@ -25,6 +25,7 @@ pub const HSW_MODE_DEFAULT: u32 = 0;
 pub const HSW_MODE_HALO2_INTERNALS: u32 = 1;
 pub const HSW_MAX_BREAKS: usize = 8;
 pub const HSW_CELL_BYTES: usize = 32;
+pub const HSW_GADGET_WHOLE_DIGEST: u32 = 1;
 
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]
@@ -81,6 +82,42 @@ pub struct hsw_witness_args {
     pub d_lookup: *mut c_void,
     pub flags: u32,
     pub pack: *const hsw_pack_plan,
+    /// whole-digest streams: blocks per digest / cells and lookup cells skipped between digests (0 = off)
+    pub frame_every: u64,
+    pub frame_cells: u64,
+    pub frame_lookups: u64,
+}
+
+/// Cell counts of the frame `digest` puts around its block loop (reference src/lib.rs:122-178, 294-341).
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_frame_shape {
+    pub n_blocks: u64,
+    pub prologue_cells: u64,
+    pub epilogue_cells: u64,
+    pub prologue_lookups: u64,
+    pub epilogue_lookups: u64,
+    pub prologue_calls: u64,
+    pub epilogue_calls: u64,
+    pub digest_cells: u64,
+    pub digest_lookups: u64,
+}
+
+/// One `digest()` call for `hsw_witness_frames`.
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_frame_desc {
+    pub input_len: u64,
+    pub first_block: u64,
+    pub prologue_cell: u64,
+    pub epilogue_cell: u64,
+    pub prologue_lookup: u64,
+    pub epilogue_lookup: u64,
+    pub zero_cell: u64,
+    pub n_blocks: u32,
+    pub num_round: u32,
+    pub precomputed_round: u32,
+    pub is_input_range_check: u32,
 }
 
 #[repr(C)]
@@ -103,6 +140,14 @@ pub struct hsw_hash_result {
     pub num_round: usize,
     pub target_round: usize,
     pub output_bytes: [u8; 32],
+    /// HSW_GADGET_WHOLE_DIGEST: section starts of this digest in the gate / lookup streams (cells)
+    pub prologue_cell: u64,
+    pub block_cell: u64,
+    pub epilogue_cell: u64,
+    pub end_cell: u64,
+    pub prologue_lookup: u64,
+    pub block_lookup: u64,
+    pub epilogue_lookup: u64,
 }
 
 #[repr(C)]
@@ -116,6 +161,11 @@ pub struct hsw_gadget_view {
     pub capacity_blocks: usize,
     pub num_limb_sum: u64,
     pub cur_hash_idx: usize,
+    pub gate_cells: u64,
+    pub gate_capacity: u64,
+    pub d_lookup: *mut c_void,
+    pub lookup_cells: u64,
+    pub lookup_capacity: u64,
 }
 
 extern "C" {
@@ -163,7 +213,16 @@ extern "C" {
                               init_state_out: *mut u32, info: *mut hsw_digest_info) -> c_int;
     pub fn hsw_gadget_create(e: *mut hsw_engine, max_variable_byte_sizes: *const usize, n_hashes: usize,
                              is_input_range_check: c_int, out: *mut *mut hsw_gadget) -> c_int;
+    pub fn hsw_gadget_create_ex(e: *mut hsw_engine, max_variable_byte_sizes: *const usize, n_hashes: usize,
+                                is_input_range_check: c_int, flags: u32, out: *mut *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
+    pub fn hsw_frame_query(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
+                           out: *mut hsw_frame_shape) -> c_int;
+    pub fn hsw_frame_tape(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
+                          section: c_int, lens_out: *mut u8, cap: usize, n_calls: *mut usize) -> c_int;
+    pub fn hsw_witness_frames(e: *mut hsw_engine, descs: *const hsw_frame_desc, n: usize, d_blocks: *const u8,
+                              d_pre_states: *const u32, d_next_states: *const u32, d_gate: *mut c_void,
+                              d_lookup: *mut c_void, flags: u32) -> c_int;
     pub fn hsw_gadget_digest(g: *mut hsw_gadget, input: *const u8, input_len: usize,
                              precomputed_input_len: usize, result: *mut hsw_hash_result) -> c_int;
     pub fn hsw_gadget_digest_batch(g: *mut hsw_gadget, n: usize, inputs: *const *const u8,

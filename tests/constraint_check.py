@@ -119,3 +119,54 @@ def chip_in_call_order(xp, col_array, n_blocks, LC, ncols):
     flat = col_array[..., 0].transpose(0, 1) if xp is not np else col_array[..., 0].T      # (rows, ncols)
     flat = flat.reshape(rows * ncols)[: n_blocks * LC]
     return flat.reshape(n_blocks, LC)
+
+
+# ---------------------------------------------------------------------------
+# Whole-digest streams: prologue | zero cell | blocks | epilogue.
+P_INT = sum(v << (64 * i) for i, v in enumerate(P_LIMBS))
+
+
+def cells_to_int(a):
+    """(n,4) uint64 canonical limbs -> list of Python ints."""
+    a = np.asarray(a, dtype=np.uint64)
+    l0, l1, l2, l3 = (a[:, i].tolist() for i in range(4))
+    return [w | (x << 64) | (y << 128) | (z << 192) for w, x, y, z in zip(l0, l1, l2, l3)]
+
+
+def check_whole_stream(ref, gate, lookup, dense, spread, spread_table, num_bits_lookup=8, ncols=2):
+    """MockProver-style check of a whole-digest witness (gate stream, lookup-advice stream,
+    chip columns) against the constraint STRUCTURE recorded by oracle.digest_cells(record=True)
+    (`ref`): every gate row, copy constraint, constant, range bound, chip tie, both lookup
+    tables.  No oracle-computed VALUE is used.  Returns the number of constraints checked."""
+    cs = ref["cs"]
+    g = cells_to_int(gate)
+    assert all(v < P_INT for v in g), "non-canonical cell"
+    n = 0
+    for r in ref["gate_rows"].tolist():
+        assert (g[r] + g[r + 1] * g[r + 2] - g[r + 3]) % P_INT == 0, "gate row at cell %d violated" % r
+    n += len(ref["gate_rows"])
+    for a, b in cs["eq"].tolist():
+        assert a >= 0 and b >= 0, "whole-digest streams have no cells outside the stream"
+        assert g[a] == g[b], "copy constraint (%d, %d) violated" % (a, b)
+    n += len(cs["eq"])
+    for c, k in cs["const"].tolist():
+        assert g[c] == (k if k >= 0 else P_INT + k), "constant at cell %d differs" % c
+    n += len(cs["const"])
+    for c, bits in cs["range"].tolist():
+        assert g[c] < (1 << bits), "range bound at cell %d violated" % c
+    n += len(cs["range"])
+    # chip columns: limb call j -> (column j % ncols, row j // ncols); tied to gate cells; a table row
+    tab = {int(d): int(s) for d, s in zip(*spread_table)}
+    dl, sl = np.asarray(dense), np.asarray(spread)
+    for j, (dc, sc) in enumerate(cs["chip"].tolist()):
+        dv, sv = dl[j % ncols, j // ncols], sl[j % ncols, j // ncols]
+        assert not dv[1:].any() and not sv[1:].any()
+        assert int(dv[0]) == g[dc] and int(sv[0]) == g[sc], "chip cell of limb call %d not tied" % j
+        assert tab[int(dv[0])] == int(sv[0]), "(dense, spread) of limb call %d is not a table row" % j
+    n += 3 * len(cs["chip"])
+    lk = cells_to_int(lookup)
+    assert len(lk) == len(cs["lookup_src"])
+    for j, src in enumerate(cs["lookup_src"].tolist()):
+        assert lk[j] == g[src] and lk[j] < 65536, "lookup entry %d" % j
+    n += 2 * len(lk)
+    return n

@@ -38,6 +38,32 @@ int main() {
             CHECK(hsw_chip_rows(&s, 5, 7) == (5 % 3 + (uint64_t)s.limb_calls_per_block * 7 + 2) / 3);
         }
     }
+    {   // digest frame arithmetic: counts and tapes with exact-size buffers
+        hsw_shape si, sd;
+        CHECK(hsw_shape_query_ex(8, 2, HSW_MODE_HALO2_INTERNALS, &si) == HSW_OK);
+        CHECK(hsw_shape_query_ex(8, 2, HSW_MODE_DEFAULT, &sd) == HSW_OK);
+        hsw_frame_shape fs;
+        CHECK(hsw_frame_query(&sd, 64, 0, &fs) == HSW_ERR_INVALID_ARG);      // frames are halo2-base internals
+        CHECK(hsw_frame_query(&si, 100, 0, &fs) == HSW_ERR_SHAPE);
+        for (size_t maxb : {64u, 128u, 1024u}) {
+            for (int rc = 0; rc < 2; rc++) {
+                CHECK(hsw_frame_query(&si, maxb, rc, &fs) == HSW_OK);
+                CHECK(fs.prologue_cells == 46 + maxb * (rc ? 5 : 1) && fs.epilogue_cells == 76 * (maxb / 64 + 1) + 288);
+                for (int section = 0; section < 2; section++) {
+                    size_t n = 0;
+                    CHECK(hsw_frame_tape(&si, maxb, rc, section, nullptr, 0, &n) == HSW_OK);
+                    CHECK(n == (section ? fs.epilogue_calls : fs.prologue_calls));
+                    std::vector<uint8_t> lens(n);
+                    CHECK(hsw_frame_tape(&si, maxb, rc, section, lens.data(), n, nullptr) == HSW_OK);
+                    CHECK(hsw_frame_tape(&si, maxb, rc, section, lens.data(), n - 1, nullptr) == HSW_ERR_INVALID_ARG);
+                    size_t cells = 0;
+                    for (uint8_t l : lens) cells += l;
+                    CHECK(cells == (section ? fs.epilogue_cells : fs.prologue_cells));
+                }
+                CHECK(hsw_frame_tape(&si, maxb, rc, 2, nullptr, 0, nullptr) == HSW_ERR_INVALID_ARG);
+            }
+        }
+    }
     hsw_shape bad;
     CHECK(hsw_shape_query(3, 2, &bad) == HSW_ERR_SHAPE);
     CHECK(hsw_shape_query(8, 0, &bad) == HSW_ERR_SHAPE);

@@ -1,0 +1,170 @@
+"""SURVEY 8 f4 on the GPU: a gadget context created with HSW_GADGET_WHOLE_DIGEST emits
+EVERY advice cell Sha256DynamicConfig::digest allocates -- prologue (lib.rs:122-178), the
+Context's zero cell, the blocks, the epilogue (lib.rs:294-341) -- as one stream, plus the
+lookup-advice stream.  Checked bit for bit against the oracle (assumptions A1-A4) and,
+independently of any oracle value, against the recorded constraint structure."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.constraint_check import check_whole_stream
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+@pytest.fixture(scope="module")
+def eng_int(hsw):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    e = hsw.WitnessEngine(0, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    yield e
+    e.close()
+
+
+CASES = [  # (messages, max sizes, precomputed, input range checks, one batch call?)
+    ([b"abc"], [64], None, False, True),
+    ([b"abc", b""], [128, 128], None, True, False),               # the reference's TestCircuit (lib.rs:455-466)
+    ([b"abc", b""], [128, 128], None, True, True),                # same, as ONE launch (equal sizes -> framed run)
+    ([bytes([1] * 56)], [192], None, True, True),
+    ([bytes(range(200))], [128], [128], False, True),             # precomputed prefix
+    ([bytes(range(119)), b"xy", b"q" * 70], [128, 64, 128], None, False, True),   # three runs in one batch
+    ([bytes([7] * 200)], [128], [192], False, True),              # target_round = 1 after 3 precomputed rounds
+]
+
+
+def _run(hsw, eng, msgs, sizes, pre, rc, batch, repr_flag=0):
+    cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True)
+    if repr_flag:
+        cfg.set_repr(repr_flag)
+    pre = pre or [None] * len(msgs)
+    res = cfg.digest_batch(msgs, pre) if batch else [cfg.digest(m, p) for m, p in zip(msgs, pre)]
+    st = cfg.streams()
+    v = cfg.view()
+    cfg.close()
+    return res, st, v
+
+
+@pytest.mark.parametrize("msgs,sizes,pre,rc,batch", CASES)
+def test_whole_digest_stream_matches_oracle(hsw, oracle, eng_int, msgs, sizes, pre, rc, batch):
+    res, st, v = _run(hsw, eng_int, msgs, sizes, pre, rc, batch)
+    ref = oracle.digest_cells(msgs, sizes, pre, rc, record=True)
+    for m, r, d in zip(msgs, res, ref["digests"]):
+        assert r.output_bytes == hashlib.sha256(m).digest() == d
+    assert int(v.gate_cells) == len(ref["gate"]) == int(v.gate_capacity)
+    assert int(v.lookup_cells) == len(ref["lookup"]) == int(v.lookup_capacity)
+    # sections where the oracle has them
+    for r, lay in zip(res, ref["layouts"]):
+        assert r.prologue_cell == lay["gate0"]
+        assert r.block_cell == lay["gate0"] + lay["prologue_cells"] + lay["zero_cells"]
+        assert r.epilogue_cell == r.block_cell + lay["block_cells"]
+        assert r.end_cell == r.epilogue_cell + lay["epilogue_cells"]
+        assert r.prologue_lookup == lay["lookup0"]
+        assert r.block_lookup == lay["lookup0"] + lay["prologue_lookups"]
+        assert r.epilogue_lookup == r.block_lookup + lay["block_lookups"]
+    bad = np.nonzero((st["gate"] != ref["gate"]).any(axis=1))[0]
+    assert len(bad) == 0, "first differing gate cells: %s" % bad[:8]
+    assert np.array_equal(st["lookup"], ref["lookup"])
+    assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]])
+    assert np.array_equal(st["spread"], ref["spread"][:, : st["rows"]])
+    # and without trusting any oracle VALUE: the GPU stream satisfies the recorded structure
+    n = check_whole_stream(ref, st["gate"], st["lookup"], st["dense"], st["spread"], hsw._native.spread_table(8))
+    assert n > 80000 * sum(s // 64 for s in sizes)
+    # ... and carries the public facts of these inputs
+    g = st["gate"]
+    for m, r, p in zip(msgs, res, pre or [0] * len(msgs)):
+        assert int(g[r.prologue_cell, 0]) == len(m)                                  # AssignedHashResult.input_len
+        b0 = r.prologue_cell + 46
+        assert bytes(g[b0: b0 + r.n_blocks * 64, 0].astype(np.uint8)) == r.input_bytes
+        out0 = r.epilogue_cell + 76 * (r.n_blocks + 1)
+        digest_cells = [out0 + 36 * w + 5 * i for w in range(8) for i in range(4)]   # AssignedHashResult.output_bytes
+        assert bytes(g[digest_cells, 0].astype(np.uint8)) == hashlib.sha256(m).digest()
+
+
+def test_whole_digest_reference_kats(hsw, oracle, eng_int):
+    """Every digest-level vector the reference's tests hold, through the whole-digest path,
+    two per context like TestCircuit (lib.rs:496-611)."""
+    vecs = KATS["vectors"]
+    for i in range(0, len(vecs), 2):
+        pair = [vecs[i], vecs[(i + 1) % len(vecs)]]
+        msgs = [bytes.fromhex(v["input_hex"]) for v in pair]
+        pres = [v.get("precomputed_input_len", 0) for v in pair]
+        sizes = [max(128, ((len(m) + 9 + 63) // 64) * 64 - p) for m, p in zip(msgs, pres)]
+        res, st, _ = _run(hsw, eng_int, msgs, sizes, pres, True, True)
+        for v, r in zip(pair, res):
+            assert r.output_bytes.hex() == v["digest_hex"]
+        ref = oracle.digest_cells(msgs, sizes, pres, True)
+        assert np.array_equal(st["gate"], ref["gate"]) and np.array_equal(st["lookup"], ref["lookup"])
+
+
+def test_whole_digest_montgomery(hsw, oracle, eng_int):
+    N = hsw._native
+    msgs, sizes = [b"abc", bytes(range(100))], [64, 192]
+    res, st, _ = _run(hsw, eng_int, msgs, sizes, None, True, True, N.HSW_REPR_MONTGOMERY)
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    assert np.array_equal(st["gate"], oracle.to_montgomery(ref["gate"]))
+    assert np.array_equal(st["lookup"], oracle.to_montgomery(ref["lookup"]))
+    assert np.array_equal(st["dense"], oracle.to_montgomery(ref["dense"])[:, : st["rows"]])
+    for m, r in zip(msgs, res):
+        assert r.output_bytes == hashlib.sha256(m).digest()
+
+
+def test_whole_digest_bench_circuit(hsw, oracle, eng_int):
+    """benches/digest.rs:103-129: one 56-byte message, max 1024 B (16 blocks), input range checks:
+    1,116,315 gate cells + 53,059 lookup cells, in 9 columns' worth of rows."""
+    msg = bytes([1] * 56)
+    res, st, v = _run(hsw, eng_int, [msg], [1024], None, True, True)
+    assert int(v.gate_cells) == 1116315 and int(v.lookup_cells) == 53059
+    ref = oracle.digest_cells([msg], [1024], None, True)
+    assert np.array_equal(st["gate"], ref["gate"]) and np.array_equal(st["lookup"], ref["lookup"])
+    assert res[0].output_bytes == hashlib.sha256(msg).digest()
+
+
+def test_whole_digest_many_small_digests(hsw, oracle, eng_int):
+    """512 single-block digests as one framed launch + one frame launch (batch path)."""
+    rng = np.random.default_rng(0xF4)
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 56)), dtype=np.uint8).tobytes() for _ in range(512)]
+    res, st, v = _run(hsw, eng_int, msgs, [64] * 512, None, False, True)
+    for m, r in zip(msgs, res):
+        assert r.output_bytes == hashlib.sha256(m).digest()
+    ref = oracle.digest_cells(msgs[:3], [64] * 3, None, False)
+    n3 = len(ref["gate"])
+    assert np.array_equal(st["gate"][:n3], ref["gate"])
+    # every digest's stream is the same function of its message: compare digest #400 with a fresh context
+    one = oracle.digest_cells([msgs[400]], [64], None, False)
+    r = res[400]
+    a = st["gate"][r.prologue_cell: r.end_cell]
+    b = np.delete(one["gate"], 110, axis=0)            # a fresh context has its zero cell after the 110 prologue cells
+    # chip-independent comparison: gate cells do not depend on the cursor
+    assert np.array_equal(a, b)
+
+
+def test_frame_argument_errors(hsw, eng_int, engine_factory):
+    N = hsw._native
+    L = eng_int.lib
+    d = N.FrameDesc()
+    d.input_len, d.n_blocks, d.num_round, d.precomputed_round = 3, 1, 2, 0          # num_round must be 1
+    d.zero_cell = N.NO_CELL
+    import torch
+    buf = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    p = buf.data_ptr()
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_INVALID_ARG
+    d.num_round, d.n_blocks = 1, 0
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_UNSUPPORTED
+    d.n_blocks, d.input_len, d.num_round = 1, 100, 2                                 # needs 2 blocks, max is 1
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_TOO_LARGE
+    d.input_len, d.num_round = 3, 1
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, N.HSW_REPR_COMPACT64) == N.HSW_ERR_UNSUPPORTED
+    plain = engine_factory(8, 2)                                                     # not in internals mode
+    assert L.hsw_witness_frames(plain.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_INVALID_ARG
+    with pytest.raises(N.HswError):
+        hsw.Sha256DynamicConfig(plain, [64], whole_digest=True)
+    cfg = hsw.Sha256DynamicConfig(eng_int, [64], whole_digest=True)
+    with pytest.raises(N.HswError):
+        cfg.set_repr(N.HSW_REPR_COMPACT64)
+    cfg.close()
