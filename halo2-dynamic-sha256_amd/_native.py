@@ -28,7 +28,7 @@ HSW_HOST_REGISTER = 8
 HSW_REPR_COMPACT64 = 16
 HSW_MODE_DEFAULT = 0
 HSW_MODE_HALO2_INTERNALS = 1
-HSW_MAX_BREAKS = 8
+HSW_MAX_BREAKS = 16
 HSW_CELL_BYTES = 32
 HSW_GADGET_WHOLE_DIGEST = 1
 NO_CELL = (1 << 64) - 1
@@ -51,7 +51,7 @@ class Shape(C.Structure):
 
 class PackPlan(C.Structure):
     _fields_ = [("n_breaks", C.c_uint32), ("columns_touched", C.c_uint32),
-                ("break_cell", C.c_uint64 * 8), ("break_gap", C.c_uint64 * 8),
+                ("break_cell", C.c_uint64 * HSW_MAX_BREAKS), ("break_gap", C.c_uint64 * HSW_MAX_BREAKS),
                 ("span_cells", C.c_uint64), ("end_row", C.c_uint64)]
 
 
@@ -97,7 +97,8 @@ class GadgetView(C.Structure):
                 ("d_next_states", C.c_void_p), ("chip_col_stride", C.c_size_t), ("blocks_done", C.c_size_t),
                 ("capacity_blocks", C.c_size_t), ("num_limb_sum", C.c_uint64), ("cur_hash_idx", C.c_size_t),
                 ("gate_cells", C.c_uint64), ("gate_capacity", C.c_uint64), ("d_lookup", C.c_void_p),
-                ("lookup_cells", C.c_uint64), ("lookup_capacity", C.c_uint64)]
+                ("lookup_cells", C.c_uint64), ("lookup_capacity", C.c_uint64),
+                ("max_rows", C.c_uint64), ("columns", C.c_uint64)]
 
 
 # every symbol include/hsw.h declares (tests check the library exports them all)
@@ -112,6 +113,7 @@ SYMBOLS = (
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
+    "hsw_gadget_set_columns", "hsw_gadget_cell_position",
 )
 
 
@@ -221,7 +223,12 @@ def lib():
         L.hsw_frame_tape.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_int, C.c_int, vp, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
         L.hsw_witness_frames.restype = C.c_int
-        L.hsw_witness_frames.argtypes = [vp, C.POINTER(FrameDesc), C.c_size_t, vp, vp, vp, vp, vp, C.c_uint32]
+        L.hsw_witness_frames.argtypes = [vp, C.POINTER(FrameDesc), C.c_size_t, vp, vp, vp, vp, vp,
+                                         C.POINTER(PackPlan), C.c_uint32]
+        L.hsw_gadget_set_columns.restype = C.c_int
+        L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_gadget_cell_position.restype = C.c_int
+        L.hsw_gadget_cell_position.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.hsw_gadget_create_ex.restype = C.c_int
         L.hsw_gadget_create_ex.argtypes = [vp, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_uint32,
                                            C.POINTER(vp)]

@@ -371,6 +371,11 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
         return set_err(e, HSW_ERR_INVALID_ARG, "lookup buffer not 16-byte aligned");
     if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS)
         return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    if (args->pack)      // the kernel applies at most two breaks inside one block
+        for (uint32_t k = 0; k + 2 < args->pack->n_breaks; k++)
+            if (args->pack->break_cell[k] != 0 &&       // breaks at cell 0 are plain offsets of the whole call
+                args->pack->break_cell[k + 2] - args->pack->break_cell[k] < e->shape.gate_cells_per_block)
+                return set_err(e, HSW_ERR_UNSUPPORTED, "more than two column breaks inside one block (max_rows too small)");
     if (args->frame_every) {
         if (e->mode != HSW_MODE_HALO2_INTERNALS)
             return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
@@ -543,7 +548,7 @@ static int ensure_inv_table(hsw_engine *e, size_t n) {
 
 int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
                        const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
-                       void *d_lookup, uint32_t flags) {
+                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags) {
     if (!e) return HSW_ERR_INVALID_ARG;
     if (n == 0) return HSW_OK;
     if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate)
@@ -555,6 +560,12 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
         return set_err(e, HSW_ERR_UNSUPPORTED, "digest frames hold full-width cells: no HSW_REPR_COMPACT64");
     if (((uintptr_t)d_gate & 15u) || ((uintptr_t)d_lookup & 15u))
         return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
+    if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    hsw::FrameBreaks brk{};
+    if (pack) {
+        brk.n = pack->n_breaks;
+        for (uint32_t k = 0; k < pack->n_breaks; k++) { brk.cell[k] = pack->break_cell[k]; brk.gap[k] = pack->break_gap[k]; }
+    }
     size_t max_blocks = 0;
     e->h_frame_descs.resize(n);
     for (size_t i = 0; i < n; i++) {
@@ -594,7 +605,7 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipMemcpyAsync", he);
     const bool mont = (flags & HSW_REPR_MONTGOMERY) != 0;
     he = hsw::launch_frames(e->d_frame_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
-                            d_gate, d_lookup, mont, e->stream);
+                            d_gate, d_lookup, brk, mont, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_frame_kernel", he);
     return HSW_OK;
 }

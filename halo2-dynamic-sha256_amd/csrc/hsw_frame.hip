@@ -58,9 +58,16 @@ template <bool MONT>
 struct Out {
     uint4 *gate;
     uint4 *lookup;      // may be null
-    DEV void cell(u64 at, u64 v) const { put(gate, at, fe_small<MONT>(v)); }
-    DEV void cell_signed(u64 at, bool neg, u64 mag) const { put(gate, at, fe_signed<MONT>(neg, mag)); }
-    DEV void cell_fe(u64 at, const Fe8 &v) const { put(gate, at, v); }
+    const FrameBreaks *brk;
+    // FlexGate column packing (A3-iii): stream cell `at` sits at `at` + the gaps of all breaks at or before it
+    DEV u64 place(u64 at) const {
+        u64 gap = 0;
+        for (u32 k = 0; k < brk->n; k++) gap += brk->cell[k] <= at ? brk->gap[k] : 0;
+        return at + gap;
+    }
+    DEV void cell(u64 at, u64 v) const { put(gate, place(at), fe_small<MONT>(v)); }
+    DEV void cell_signed(u64 at, bool neg, u64 mag) const { put(gate, place(at), fe_signed<MONT>(neg, mag)); }
+    DEV void cell_fe(u64 at, const Fe8 &v) const { put(gate, place(at), v); }
     DEV void look(u64 at, u64 v) const { if (lookup) put(lookup, at, fe_small<MONT>(v)); }
     // range_check(byte, 8): lookup byte; [0, byte, 2^8, byte * 2^8]; lookup the product
     DEV void range_check8(u64 at, u64 lk, u32 byte) const {
@@ -75,10 +82,11 @@ struct Out {
 template <bool MONT>
 __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, const uint8_t *blocks,
                                                         const u32 *pre_states, const u32 *next_states,
-                                                        const u64 *inv_tbl, uint4 *gate, uint4 *lookup) {
+                                                        const u64 *inv_tbl, uint4 *gate, uint4 *lookup,
+                                                        FrameBreaks brk) {
     using namespace frame;
     const FrameDesc d = descs[blockIdx.x];
-    const Out<MONT> o{gate, lookup};
+    const Out<MONT> o{gate, lookup, &brk};
     const u32 tid = threadIdx.x, nthreads = blockDim.x;
     const u64 P0 = d.prologue_cell, E0 = d.epilogue_cell;
     const u32 N = d.n_blocks;
@@ -175,17 +183,17 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
 
 hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
                          const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
-                         bool montgomery, hipStream_t stream) {
+                         const FrameBreaks &brk, bool montgomery, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const dim3 grid((unsigned)n), block(256);
     if (montgomery)
         hipLaunchKernelGGL(hsw_frame_kernel<true>, grid, block, 0, stream, d_descs, blocks, pre_states, next_states,
                            reinterpret_cast<const u64 *>(d_inv_tbl), reinterpret_cast<uint4 *>(gate),
-                           reinterpret_cast<uint4 *>(lookup));
+                           reinterpret_cast<uint4 *>(lookup), brk);
     else
         hipLaunchKernelGGL(hsw_frame_kernel<false>, grid, block, 0, stream, d_descs, blocks, pre_states, next_states,
                            reinterpret_cast<const u64 *>(d_inv_tbl), reinterpret_cast<uint4 *>(gate),
-                           reinterpret_cast<uint4 *>(lookup));
+                           reinterpret_cast<uint4 *>(lookup), brk);
     return hipGetLastError();
 }
 

@@ -76,5 +76,13 @@ struct FrameDesc {
     uint32_t range_check_inputs;
 };
 
+// FlexGate column breaks applied to frame cells (absolute gate-stream indices), like
+// ExpandParams::break_cell / break_gap.
+struct FrameBreaks {
+    uint32_t n;
+    uint64_t cell[16];
+    uint64_t gap[16];
+};
+
 }  // namespace hsw
 #endif

@@ -187,6 +187,70 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     return HSW_OK;
 }
 
+int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint64_t rows) {
+    if (!whole || blocks_done != 0 || gate_cursor != 0) return HSW_ERR_INVALID_ARG;
+    const uint64_t G = shape.gate_cells_per_block;
+    if (rows < G + 16) return HSW_ERR_INVALID_ARG;        // keeps a block inside <= 2 columns (kernel: <= 2 breaks per block)
+    size_t n = 0;
+    if (hsw_gate_tape(&shape, nullptr, 0, &n) != HSW_OK) return HSW_ERR_INVALID_ARG;
+    std::vector<uint8_t> block_tape(n);
+    hsw_gate_tape(&shape, block_tape.data(), n, nullptr);
+    std::vector<uint64_t> bc, bg;
+    uint64_t row = 0, cell = 0;
+    auto walk = [&](const std::vector<uint8_t> &lens) {
+        for (uint8_t len : lens) {
+            if (row + len >= rows) {                      // halo2-lib v0.2.x assign_region: next column (A3-iii)
+                bc.push_back(cell); bg.push_back(rows - row);
+                row = 0;
+            }
+            row += len; cell += len;
+        }
+    };
+    bool zero = false;
+    for (size_t b : sizes) {
+        for (int section = 0; section < 2; section++) {
+            if (section == 1) {
+                if (!zero) { walk({1}); zero = true; }    // Context.zero_cell, first load_zero
+                for (size_t k = 0; k < b / 64; k++) {
+                    if (row + G + 8 < rows) { row += G; cell += G; }
+                    else walk(block_tape);
+                }
+            }
+            size_t m = 0;
+            int rc = hsw_frame_tape(&shape, b, rc_inputs ? 1 : 0, section, nullptr, 0, &m);
+            if (rc != HSW_OK) return rc;
+            std::vector<uint8_t> t(m);
+            hsw_frame_tape(&shape, b, rc_inputs ? 1 : 0, section, t.data(), m, nullptr);
+            walk(t);
+        }
+    }
+    if (bc.size() > HSW_MAX_BREAKS) return HSW_ERR_TOO_LARGE;
+    const uint64_t cols = bc.size() + 1;
+    int device = 0;
+    hsw_engine_stream(engine, nullptr, &device);
+    DeviceScope ds2(device);
+    if (!ds2.ok) return HSW_ERR_NO_DEVICE;
+    void *img = nullptr;
+    hipError_t he = hipMalloc(&img, (size_t)(cols * rows) * HSW_CELL_BYTES);
+    if (he == hipSuccess) he = hipMemset(img, 0, (size_t)(cols * rows) * HSW_CELL_BYTES);   // unassigned advice cells are 0
+    if (he != hipSuccess) { if (img) (void)hipFree(img); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
+    (void)hipFree(d_gate);
+    d_gate = img;
+    max_rows = rows;
+    columns = cols;
+    break_cell.swap(bc);
+    break_gap.swap(bg);
+    return HSW_OK;
+}
+
+void Context::position(uint64_t cell, uint64_t *column, uint64_t *row) const {
+    uint64_t at = cell;
+    for (size_t k = 0; k < break_cell.size(); k++)
+        if (break_cell[k] <= cell) at += break_gap[k];
+    if (max_rows) { if (column) *column = at / max_rows; if (row) *row = at % max_rows; }
+    else { if (column) *column = 0; if (row) *row = at; }
+}
+
 int Sha256DynamicConfig::digest(Context &ctx, const uint8_t *input, size_t input_len,
                                 size_t precomputed_input_len, AssignedHashResult *result) {
     return digest_batch(ctx, 1, &input, &input_len, &precomputed_input_len, result);
@@ -338,13 +402,31 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                 a.frame_every = nb;
                 a.frame_cells = fss[i].epilogue_cells + fss[i].prologue_cells;
                 a.frame_lookups = fss[i].epilogue_lookups + fss[i].prologue_lookups;
+                hsw_pack_plan plan{};
+                if (ctx.max_rows) {
+                    // column breaks relative to this launch's first cell; breaks before it are pure offsets
+                    const uint64_t base = results[i].block_cell;
+                    plan.n_breaks = (uint32_t)ctx.break_cell.size();
+                    for (size_t k = 0; k < ctx.break_cell.size(); k++) {
+                        plan.break_cell[k] = ctx.break_cell[k] > base ? ctx.break_cell[k] - base : 0;
+                        plan.break_gap[k] = ctx.break_gap[k];
+                    }
+                    a.pack = &plan;
+                }
                 rc = hsw_witness_blocks_ex(ctx.engine, &a);
                 ob += run_blocks;
                 i = j;
             }
-            if (rc == HSW_OK)
+            if (rc == HSW_OK) {
+                hsw_pack_plan plan{};
+                plan.n_breaks = (uint32_t)ctx.break_cell.size();
+                for (size_t k = 0; k < ctx.break_cell.size(); k++) {
+                    plan.break_cell[k] = ctx.break_cell[k];
+                    plan.break_gap[k] = ctx.break_gap[k];
+                }
                 rc = hsw_witness_frames(ctx.engine, frames.data(), n, ctx.d_blocks, ctx.d_pre_states, ctx.d_next_states,
-                                        ctx.d_gate, ctx.d_lookup, ctx.repr_flags);
+                                        ctx.d_gate, ctx.d_lookup, ctx.max_rows ? &plan : nullptr, ctx.repr_flags);
+            }
             if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
         }
         if (rc != HSW_OK) break;
@@ -496,6 +578,8 @@ int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
     view->d_lookup = g->ctx->d_lookup;
     view->lookup_cells = g->ctx->lookup_cursor;
     view->lookup_capacity = g->ctx->lookup_capacity;
+    view->max_rows = g->ctx->max_rows;
+    view->columns = g->ctx->columns;
     return HSW_OK;
 }
 
@@ -507,6 +591,19 @@ int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t 
         if (cap < b.size()) return HSW_ERR_INVALID_ARG;
         if (!b.empty()) std::memcpy(out, b.data(), b.size());
     }
+    return HSW_OK;
+}
+
+int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    const int rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
+    if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
+    return rc;
+}
+
+int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    g->ctx->position(cell, column, row);
     return HSW_OK;
 }
 

@@ -113,6 +113,15 @@ class Context {
     uint64_t gate_cursor = 0, gate_capacity = 0;       // cells
     void *d_lookup = nullptr;
     uint64_t lookup_cursor = 0, lookup_capacity = 0;
+    // FlexGate column image (set_columns): d_gate is `columns` advice columns of max_rows cells;
+    // stream cell i sits at i + the gaps of all breaks at or before i (assumption A3-iii)
+    uint64_t max_rows = 0, columns = 0;
+    std::vector<uint64_t> break_cell, break_gap;
+    // Lay the whole-digest stream out as FlexGate (Vertical) advice columns of max_rows usable rows.
+    // Only before the first digest.  HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns.
+    int set_columns(const std::vector<size_t> &max_variable_byte_sizes, bool is_input_range_check, uint64_t max_rows);
+    // (column, row) of stream cell i
+    void position(uint64_t cell, uint64_t *column, uint64_t *row) const;
 };
 
 }  // namespace hsw

@@ -16,7 +16,7 @@ enum : uint32_t {
     HSW_K_COMPACT = 8u,      // HSW_REPR_COMPACT64: 8-byte cells
     HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
 };
-enum { HSW_K_MAX_BREAKS = 8 };
+enum { HSW_K_MAX_BREAKS = 16 };
 
 struct ExpandParams {
     const uint8_t *blocks;        // n_blocks * 64 bytes
@@ -55,10 +55,11 @@ hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 
 struct FrameDesc;   // hsw_frame.hpp
+struct FrameBreaks;
 // d_inv_tbl: k^-1 mod p for k = 0..(largest n_blocks), 4 x u64 each, in the output representation
 hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
                          const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
-                         bool montgomery, hipStream_t stream);
+                         const FrameBreaks &brk, bool montgomery, hipStream_t stream);
 
 }  // namespace hsw
 #endif

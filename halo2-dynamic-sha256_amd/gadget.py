@@ -84,6 +84,18 @@ class Sha256DynamicConfig:
         self._n += n
         return out
 
+    def set_columns(self, max_rows):
+        """Lay the whole-digest stream out as FlexGate advice columns of max_rows rows (before the
+        first digest).  Returns the number of columns."""
+        n = C.c_uint64()
+        self._ok(self.lib.hsw_gadget_set_columns(self.h, max_rows, C.byref(n)))
+        return int(n.value)
+
+    def cell_position(self, cell):
+        c, r = C.c_uint64(), C.c_uint64()
+        self._ok(self.lib.hsw_gadget_cell_position(self.h, cell, C.byref(c), C.byref(r)))
+        return int(c.value), int(r.value)
+
     def set_repr(self, repr_flag):
         self._ok(self.lib.hsw_gadget_set_repr(self.h, repr_flag))
 
@@ -105,7 +117,10 @@ class Sha256DynamicConfig:
             return a
 
         rows = (int(v.num_limb_sum) + ncols - 1) // ncols
-        gate = grab(v.d_gate, int(v.gate_cells) if self.whole_digest else int(v.blocks_done) * G)
+        if self.whole_digest and int(v.max_rows):
+            gate = grab(v.d_gate, int(v.max_rows) * int(v.columns)).reshape(int(v.columns), int(v.max_rows), 4)
+        else:
+            gate = grab(v.d_gate, int(v.gate_cells) if self.whole_digest else int(v.blocks_done) * G)
         dense = np.stack([grab(v.d_chip_dense + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
         spread = np.stack([grab(v.d_chip_spread + c * int(v.chip_col_stride) * 32, rows) for c in range(ncols)])
         out = dict(gate=gate, dense=dense, spread=spread, rows=rows)

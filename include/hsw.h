@@ -184,7 +184,7 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
  * the breaks for n_blocks blocks whose first cell lands at `start_row` of some
  * column; hsw_witness_blocks_ex applies them while writing.
  * ------------------------------------------------------------------------ */
-#define HSW_MAX_BREAKS 8
+#define HSW_MAX_BREAKS 16
 typedef struct hsw_pack_plan {
     uint32_t n_breaks;
     uint32_t columns_touched;            /* 1 + n_breaks */
@@ -329,11 +329,13 @@ typedef struct hsw_frame_desc {   /* one digest() call */
 /* Writes the frames of n digests.  d_pre_states / d_next_states are the ones the
  * block expansion read / wrote (the candidate states of lib.rs:296 are
  * pre_states[first_block] and next_states[first_block .. first_block+n_blocks-1]);
- * descs is HOST memory.  d_lookup may be NULL.  Asynchronous on the engine's
- * stream, ordered after earlier hsw_witness_blocks calls. */
+ * descs is HOST memory.  d_lookup may be NULL.  pack (may be NULL): FlexGate column
+ * breaks in the same absolute gate-stream indices as prologue_cell / epilogue_cell;
+ * a frame cell at stream index i is written at i + the gaps of all breaks <= i.
+ * Asynchronous on the engine's stream, ordered after earlier hsw_witness_blocks calls. */
 int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
                        const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
-                       void *d_lookup, uint32_t flags);
+                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags);
 
 typedef struct hsw_gadget hsw_gadget;   /* Sha256DynamicConfig + its Context */
 
@@ -363,6 +365,7 @@ typedef struct hsw_gadget_view {
     uint64_t gate_cells, gate_capacity;
     void *d_lookup;
     uint64_t lookup_cells, lookup_capacity;
+    uint64_t max_rows, columns;         /* hsw_gadget_set_columns: d_gate is columns x max_rows cells; else 0 */
 } hsw_gadget_view;
 
 /* Sha256DynamicConfig::configure (lib.rs:49-69) + new_context (lib.rs:351-360):
@@ -376,6 +379,16 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                          int is_input_range_check, uint32_t flags, hsw_gadget **out);
 void hsw_gadget_destroy(hsw_gadget *g);
+/* HSW_GADGET_WHOLE_DIGEST, before the first digest: lay the gate stream out as the
+ * FlexGate (Vertical) advice columns themselves -- column c = cells [c*max_rows,
+ * (c+1)*max_rows) of d_gate, every assign_region call placed by the v0.2.x rule
+ * `row + len >= max_rows -> next column` (assumption A3-iii), unassigned tail rows 0.
+ * max_rows = the gate's usable rows (RangeConfig.gate.max_rows, lib.rs:355).  The
+ * layout depends only on max_variable_byte_sizes, never on the messages.
+ * HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns. */
+int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns);
+/* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
+int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);
 /* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.
  * Synchronous: returns once the streams of this hash are in HBM. */
 int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len,

@@ -23,7 +23,7 @@ pub const HSW_HOST_REGISTER: u32 = 8;
 pub const HSW_REPR_COMPACT64: u32 = 16;
 pub const HSW_MODE_DEFAULT: u32 = 0;
 pub const HSW_MODE_HALO2_INTERNALS: u32 = 1;
-pub const HSW_MAX_BREAKS: usize = 8;
+pub const HSW_MAX_BREAKS: usize = 16;
 pub const HSW_CELL_BYTES: usize = 32;
 pub const HSW_GADGET_WHOLE_DIGEST: u32 = 1;
 
@@ -166,6 +166,8 @@ pub struct hsw_gadget_view {
     pub d_lookup: *mut c_void,
     pub lookup_cells: u64,
     pub lookup_capacity: u64,
+    pub max_rows: u64,
+    pub columns: u64,
 }
 
 extern "C" {
@@ -216,13 +218,15 @@ extern "C" {
     pub fn hsw_gadget_create_ex(e: *mut hsw_engine, max_variable_byte_sizes: *const usize, n_hashes: usize,
                                 is_input_range_check: c_int, flags: u32, out: *mut *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
+    pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
+    pub fn hsw_gadget_cell_position(g: *const hsw_gadget, cell: u64, column: *mut u64, row: *mut u64) -> c_int;
     pub fn hsw_frame_query(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                            out: *mut hsw_frame_shape) -> c_int;
     pub fn hsw_frame_tape(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                           section: c_int, lens_out: *mut u8, cap: usize, n_calls: *mut usize) -> c_int;
     pub fn hsw_witness_frames(e: *mut hsw_engine, descs: *const hsw_frame_desc, n: usize, d_blocks: *const u8,
                               d_pre_states: *const u32, d_next_states: *const u32, d_gate: *mut c_void,
-                              d_lookup: *mut c_void, flags: u32) -> c_int;
+                              d_lookup: *mut c_void, pack: *const hsw_pack_plan, flags: u32) -> c_int;
     pub fn hsw_gadget_digest(g: *mut hsw_gadget, input: *const u8, input_len: usize,
                              precomputed_input_len: usize, result: *mut hsw_hash_result) -> c_int;
     pub fn hsw_gadget_digest_batch(g: *mut hsw_gadget, n: usize, inputs: *const *const u8,

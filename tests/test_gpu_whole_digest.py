@@ -153,18 +153,73 @@ def test_frame_argument_errors(hsw, eng_int, engine_factory):
     import torch
     buf = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
     p = buf.data_ptr()
-    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_INVALID_ARG
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_INVALID_ARG
     d.num_round, d.n_blocks = 1, 0
-    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_UNSUPPORTED
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_UNSUPPORTED
     d.n_blocks, d.input_len, d.num_round = 1, 100, 2                                 # needs 2 blocks, max is 1
-    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_TOO_LARGE
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_TOO_LARGE
     d.input_len, d.num_round = 3, 1
-    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, N.HSW_REPR_COMPACT64) == N.HSW_ERR_UNSUPPORTED
+    assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, N.HSW_REPR_COMPACT64) == N.HSW_ERR_UNSUPPORTED
     plain = engine_factory(8, 2)                                                     # not in internals mode
-    assert L.hsw_witness_frames(plain.h, C.byref(d), 1, p, p, p, p, p, 0) == N.HSW_ERR_INVALID_ARG
+    assert L.hsw_witness_frames(plain.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_INVALID_ARG
     with pytest.raises(N.HswError):
         hsw.Sha256DynamicConfig(plain, [64], whole_digest=True)
     cfg = hsw.Sha256DynamicConfig(eng_int, [64], whole_digest=True)
     with pytest.raises(N.HswError):
         cfg.set_repr(N.HSW_REPR_COMPACT64)
+    cfg.close()
+
+
+def _model_columns(call_lens, gate, max_rows):
+    """halo2-lib v0.2.x FlexGate::assign_region over the oracle's call tape (A3-iii):
+    `if row + len >= max_rows { column += 1; row = 0 }`.  Returns the column image."""
+    cols, col, row, pos = [np.zeros((max_rows, 4), dtype=np.uint64)], 0, 0, 0
+    for ln in call_lens.tolist():
+        if row + ln >= max_rows:
+            cols.append(np.zeros((max_rows, 4), dtype=np.uint64))
+            col, row = col + 1, 0
+        cols[col][row:row + ln] = gate[pos:pos + ln]
+        row += ln
+        pos += ln
+    assert pos == len(gate)
+    return np.stack(cols), (col, row)
+
+
+@pytest.mark.parametrize("msgs,sizes,rc,max_rows,want_cols", [
+    ([b"abc", b""], [128, 128], True, (1 << 17) - 9, 3),           # TestCircuit: NUM_ADVICE = 3 (lib.rs:487-493)
+    ([bytes([1] * 56)], [1024], True, (1 << 17) - 9, 9),           # bench circuit: NUM_ADVICE = 9 (benches/digest.rs:103-108)
+    ([b"abc", b"de", b"f" * 60], [64, 64, 128], False, 69500, None),   # a break in (nearly) every block
+])
+def test_whole_digest_as_flexgate_columns(hsw, oracle, eng_int, msgs, sizes, rc, max_rows, want_cols):
+    """f2 + f4 together: the gadget writes the literal FlexGate advice-column image of the whole
+    region (every assign_region call kept inside one column, unassigned tail rows zero)."""
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=rc, whole_digest=True)
+    ncols = cfg.set_columns(max_rows)
+    assert want_cols is None or ncols == want_cols
+    res = cfg.digest_batch(msgs, [None] * len(msgs))
+    st = cfg.streams()
+    ref = oracle.digest_cells(msgs, sizes, None, rc)
+    img, (last_col, end_row) = _model_columns(ref["call_lens"], ref["gate"], max_rows)
+    assert img.shape[0] == ncols == st["gate"].shape[0]
+    bad = np.nonzero((st["gate"] != img).any(axis=2))
+    assert len(bad[0]) == 0, "first differing (column, row): %s" % [(int(c), int(r)) for c, r in zip(*bad)][:6]
+    assert np.array_equal(st["lookup"], ref["lookup"])
+    # cell_position is the same map
+    r = res[-1]
+    assert cfg.cell_position(r.end_cell - 1) == (last_col, end_row - 1)
+    assert cfg.cell_position(0) == (0, 0)
+    for m, rr in zip(msgs, res):
+        assert rr.output_bytes == hashlib.sha256(m).digest()
+    with pytest.raises(hsw.HswError):
+        cfg.set_columns(max_rows)                  # only before the first digest
+    cfg.close()
+
+
+def test_set_columns_errors(hsw, eng_int):
+    cfg = hsw.Sha256DynamicConfig(eng_int, [64] * 40, whole_digest=True)
+    with pytest.raises(hsw.HswError):
+        cfg.set_columns(1000)                      # a block must fit two columns
+    with pytest.raises(hsw.HswError):
+        cfg.set_columns(69348 + 16)                # > HSW_MAX_BREAKS + 1 columns
+    assert cfg.set_columns(1 << 20) == 3
     cfg.close()
