@@ -347,6 +347,32 @@ def main():
         cfg.close()
         extra["config1_1KiB_message_16_blocks"]["gadget_digest_end_to_end"] = {
             "ms_per_message": dtg * 1e3, "blocks_per_s": 16 / dtg}
+        # BASELINE configs[0], the reference's own bench circuit (benches/digest.rs:103-129): one 56-byte
+        # message, max 1024 B, input range checks, k = 17 -- as the literal advice-column image of the whole
+        # region (SURVEY 8 f2 + f4, assumptions A1-A4): 9 FlexGate columns x 131,063 rows + the lookup column
+        try:
+            eng_i = hsw.WitnessEngine(local_rank, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+            cfgw = hsw.Sha256DynamicConfig(eng_i, [1024], True, whole_digest=True)
+            ncol = cfgw.set_columns((1 << 17) - 9)
+            m56 = bytes([1] * 56)
+            for _ in range(4):
+                cfgw.reset()
+                rw = cfgw.digest(m56)
+            t1 = time.perf_counter()
+            for _ in range(50):
+                cfgw.reset()
+                rw = cfgw.digest(m56)
+            dtw = (time.perf_counter() - t1) / 50
+            assert rw.output_bytes == hashlib.sha256(m56).digest()
+            vw = cfgw.view()
+            extra["config0_bench_circuit_whole_region"] = {
+                "ms_per_synthesis": dtw * 1e3, "blocks_per_s": 16 / dtw, "advice_columns": ncol,
+                "gate_cells": int(vw.gate_cells), "lookup_cells": int(vw.lookup_cells),
+                "note": "prologue + 16 blocks + epilogue of Sha256DynamicConfig::digest written as FlexGate columns in HBM"}
+            cfgw.close()
+            eng_i.close()
+        except Exception as ex:
+            extra["config0_bench_circuit_whole_region"] = {"error": repr(ex)}
 
     if not args.no_extra and rank == 0:
         # BASELINE configs[4] needs the Rust prover (create_proof at k=20): not runnable here.

@@ -41,9 +41,15 @@ struct hsw_engine {
     size_t slot_blocks = 0, slot_rows = 0;
     // digest frames (hsw_witness_frames): descriptors staged per call, and k^-1 for
     // k = 0..inv_n-1 in canonical ([0]) and Montgomery ([1]) form
-    hsw::FrameDesc *d_frame_descs = nullptr;
-    size_t frame_desc_cap = 0;
-    std::vector<hsw::FrameDesc> h_frame_descs;
+    // descriptor staging: a ring of pinned, device-mapped host buffers the kernel reads directly
+    // (no H2D copy, no stream sync unless four frame launches are already in flight)
+    struct FrameSlot {
+        hsw::FrameDesc *h = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool inflight = false;
+    } frame_slot[4];
+    unsigned frame_next = 0;
     uint64_t *d_inv_tbl[2] = {nullptr, nullptr};
     size_t inv_n = 0;
 };
@@ -260,7 +266,10 @@ void hsw_engine_destroy(hsw_engine *e) {
     {
         DeviceScope ds(e->device);
         free_pipeline(e);
-        if (e->d_frame_descs) (void)hipFree(e->d_frame_descs);
+        for (auto &fs : e->frame_slot) {
+            if (fs.h) (void)hipHostFree(fs.h);
+            if (fs.done) (void)hipEventDestroy(fs.done);
+        }
         if (e->d_inv_tbl[0]) (void)hipFree(e->d_inv_tbl[0]);
         if (e->d_inv_tbl[1]) (void)hipFree(e->d_inv_tbl[1]);
         if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -566,8 +575,29 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
         brk.n = pack->n_breaks;
         for (uint32_t k = 0; k < pack->n_breaks; k++) { brk.cell[k] = pack->break_cell[k]; brk.gap[k] = pack->break_gap[k]; }
     }
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipError_t he;
+    hsw_engine::FrameSlot &slot = e->frame_slot[e->frame_next++ & 3u];
+    if (slot.inflight) {                      // the launch that last used this slot must have read it
+        he = hipEventSynchronize(slot.done);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventSynchronize", he);
+        slot.inflight = false;
+    }
+    if (slot.cap < n) {
+        if (slot.h) (void)hipHostFree(slot.h);
+        slot.h = nullptr; slot.cap = 0;
+        size_t cap = 16;
+        while (cap < n) cap *= 2;
+        he = hipHostMalloc((void **)&slot.h, cap * sizeof(hsw::FrameDesc), hipHostMallocMapped);
+        if (he != hipSuccess) return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "hipHostMalloc", he);
+        slot.cap = cap;
+    }
+    if (!slot.done) {
+        he = hipEventCreateWithFlags(&slot.done, hipEventDisableTiming);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventCreate", he);
+    }
     size_t max_blocks = 0;
-    e->h_frame_descs.resize(n);
     for (size_t i = 0; i < n; i++) {
         const hsw_frame_desc &d = descs[i];
         if (d.n_blocks == 0) return set_err(e, HSW_ERR_UNSUPPORTED, "a digest frame needs max_variable_byte_size >= 64");
@@ -575,7 +605,7 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
             return set_err(e, HSW_ERR_INVALID_ARG, "num_round is not ceil((input_len + 9) / 64) (lib.rs:80-84)");
         if (d.precomputed_round > d.num_round || d.num_round - d.precomputed_round > d.n_blocks)
             return set_err(e, HSW_ERR_TOO_LARGE, "padded message does not fit max_variable_byte_size (lib.rs:90)");
-        hsw::FrameDesc &o = e->h_frame_descs[i];
+        hsw::FrameDesc &o = slot.h[i];
         o.input_len = d.input_len; o.first_block = d.first_block;
         o.prologue_cell = d.prologue_cell; o.epilogue_cell = d.epilogue_cell;
         o.prologue_lookup = d.prologue_lookup; o.epilogue_lookup = d.epilogue_lookup;
@@ -583,30 +613,18 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
         o.precomputed_round = d.precomputed_round; o.range_check_inputs = d.is_input_range_check ? 1u : 0u;
         if (d.n_blocks > max_blocks) max_blocks = d.n_blocks;
     }
-    DeviceScope ds(e->device);
-    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
     int rc = ensure_inv_table(e, max_blocks + 1);
     if (rc != HSW_OK) return rc;
-    hipError_t he;
-    if (e->frame_desc_cap < n) {
-        // the previous staging buffer may still be read by an earlier launch
-        if (e->d_frame_descs) { (void)hipStreamSynchronize(e->stream); (void)hipFree(e->d_frame_descs); e->d_frame_descs = nullptr; }
-        e->frame_desc_cap = 0;
-        he = hipMalloc((void **)&e->d_frame_descs, n * sizeof(hsw::FrameDesc));
-        if (he != hipSuccess) return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "hipMalloc", he);
-        e->frame_desc_cap = n;
-    } else {
-        // one staging buffer per engine: wait until the previous frame launch has consumed it
-        he = hipStreamSynchronize(e->stream);
-        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipStreamSynchronize", he);
-    }
-    he = hipMemcpyAsync(e->d_frame_descs, e->h_frame_descs.data(), n * sizeof(hsw::FrameDesc), hipMemcpyHostToDevice,
-                        e->stream);
-    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipMemcpyAsync", he);
+    hsw::FrameDesc *d_descs = nullptr;
+    he = hipHostGetDevicePointer((void **)&d_descs, slot.h, 0);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipHostGetDevicePointer", he);
     const bool mont = (flags & HSW_REPR_MONTGOMERY) != 0;
-    he = hsw::launch_frames(e->d_frame_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
+    he = hsw::launch_frames(d_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
                             d_gate, d_lookup, brk, mont, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_frame_kernel", he);
+    he = hipEventRecord(slot.done, e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
+    slot.inflight = true;
     return HSW_OK;
 }
 

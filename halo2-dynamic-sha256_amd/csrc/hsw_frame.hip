@@ -99,33 +99,43 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
         return n == 0 ? pre_states[8 * d.first_block + i] : next_states[8 * (d.first_block + n - 1) + i];
     };
 
-    // ---- prologue, fixed part: lib.rs:124-165 ----
-    if (tid == 0) {
+    // ---- prologue, fixed part: lib.rs:124-165; thread t < 46 writes cell t ----
+    {
         const u64 len = d.input_len, nr = d.num_round, pre = d.precomputed_round;
-        const u64 padded = 64 * nr, with9 = len + 9, pad = padded - with9;      // pad < 64 (lib.rs:142-144)
-        o.cell(P0 + P_LEN, len);
-        o.cell(P0 + P_NROUND, nr);
-        o.cell(P0 + P_MUL, 0); o.cell(P0 + P_MUL + 1, nr); o.cell(P0 + P_MUL + 2, 64); o.cell(P0 + P_MUL + 3, padded);
-        o.cell(P0 + P_ADD, len); o.cell(P0 + P_ADD + 1, 9); o.cell(P0 + P_ADD + 2, 1); o.cell(P0 + P_ADD + 3, with9);
-        o.cell(P0 + P_SUB, pad); o.cell(P0 + P_SUB + 1, with9); o.cell(P0 + P_SUB + 2, 1); o.cell(P0 + P_SUB + 3, padded);
+        const u64 padded = 64 * nr, with9 = len + 9, pad = padded - with9;      // pad < 64 (lib.rs:142-144; host-checked)
         // is_less_than_safe(padding_size, 64)
         const u64 shift_a = pad + 65536, shifted = shift_a - 64;
         const u64 limb0 = shifted & 0xffff, limb1 = shifted >> 16;              // limb1 = 0 <=> pad < 64
-        o.look(d.prologue_lookup, pad);
-        o.cell(P0 + P_LT, shifted); o.cell(P0 + P_LT + 1, 64); o.cell(P0 + P_LT + 2, 1); o.cell(P0 + P_LT + 3, shift_a);
-        o.cell_signed(P0 + P_LT + 4, true, 65536); o.cell(P0 + P_LT + 5, 1); o.cell(P0 + P_LT + 6, pad);
-        o.cell(P0 + P_RC32, limb0); o.cell(P0 + P_RC32 + 1, limb1); o.cell(P0 + P_RC32 + 2, 65536); o.cell(P0 + P_RC32 + 3, shifted);
-        o.look(d.prologue_lookup + 1, limb0); o.look(d.prologue_lookup + 2, limb1);
         const u64 z = limb1 == 0 ? 1 : 0;
-        o.cell(P0 + P_ISZ, z); o.cell(P0 + P_ISZ + 1, limb1);
-        o.cell(P0 + P_ISZ + 2, 1);      // is_zero's inv witness of 0 is 1; limb1 = 0 because the host checked pad < 64
-        o.cell(P0 + P_ISZ + 3, 1); o.cell(P0 + P_ISZ + 4, 0); o.cell(P0 + P_ISZ + 5, limb1);
-        o.cell(P0 + P_ISZ + 6, z); o.cell(P0 + P_ISZ + 7, 0);
-        o.cell(P0 + P_PRE, pre);
-        o.cell(P0 + P_TGT, nr - pre); o.cell(P0 + P_TGT + 1, pre); o.cell(P0 + P_TGT + 2, 1); o.cell(P0 + P_TGT + 3, nr);
-        if (d.zero_cell != ~0ull) o.cell(d.zero_cell, 0);                       // Context.zero_cell
+        if (tid < P_STATE) {
+            u64 v = 0;
+            switch (tid) {
+                case P_LEN: v = len; break;
+                case P_NROUND: v = nr; break;
+                case P_MUL: v = 0; break;      case P_MUL + 1: v = nr; break;     case P_MUL + 2: v = 64; break;  case P_MUL + 3: v = padded; break;
+                case P_ADD: v = len; break;    case P_ADD + 1: v = 9; break;      case P_ADD + 2: v = 1; break;   case P_ADD + 3: v = with9; break;
+                case P_SUB: v = pad; break;    case P_SUB + 1: v = with9; break;  case P_SUB + 2: v = 1; break;   case P_SUB + 3: v = padded; break;
+                case P_LT: v = shifted; break; case P_LT + 1: v = 64; break;      case P_LT + 2: v = 1; break;    case P_LT + 3: v = shift_a; break;
+                case P_LT + 4: v = 65536; break;   /* written as -2^16 below */   case P_LT + 5: v = 1; break;    case P_LT + 6: v = pad; break;
+                case P_RC32: v = limb0; break; case P_RC32 + 1: v = limb1; break; case P_RC32 + 2: v = 65536; break; case P_RC32 + 3: v = shifted; break;
+                case P_ISZ: v = z; break;      case P_ISZ + 1: v = limb1; break;
+                case P_ISZ + 2: v = 1; break;  // is_zero's inv witness of 0 is 1
+                case P_ISZ + 3: v = 1; break;  case P_ISZ + 4: v = 0; break;      case P_ISZ + 5: v = limb1; break;
+                case P_ISZ + 6: v = z; break;  case P_ISZ + 7: v = 0; break;
+                case P_PRE: v = pre; break;
+                case P_TGT: v = nr - pre; break; case P_TGT + 1: v = pre; break;  case P_TGT + 2: v = 1; break;   case P_TGT + 3: v = nr; break;
+                default: break;
+            }
+            o.cell_signed(P0 + tid, tid == P_LT + 4, v);
+        } else if (tid < P_BYTES) {
+            o.cell(P0 + tid, state_word(0, tid - P_STATE));                      // lib.rs:162-165
+        } else if (tid == 64) {
+            o.look(d.prologue_lookup, pad);
+            o.look(d.prologue_lookup + 1, limb0);
+            o.look(d.prologue_lookup + 2, limb1);
+            if (d.zero_cell != ~0ull) o.cell(d.zero_cell, 0);                   // Context.zero_cell
+        }
     }
-    if (tid >= 64 && tid < 72) o.cell(P0 + P_STATE + (tid - 64), state_word(0, tid - 64));
 
     // ---- prologue, input bytes: lib.rs:170-178 ----
     for (u64 i = tid; i < max_bytes; i += nthreads) {

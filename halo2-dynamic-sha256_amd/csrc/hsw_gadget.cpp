@@ -601,6 +601,20 @@ int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns
     return rc;
 }
 
+int hsw_gadget_reset(hsw_gadget *g) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    const int rc = hsw_engine_synchronize(g->ctx->engine);
+    if (rc != HSW_OK) return rc;
+    hsw::Context &c = *g->ctx;
+    c.blocks_done = 0;
+    c.num_limb_sum = 0;                 // spread.rs:70-71
+    c.gate_cursor = c.lookup_cursor = 0;
+    c.zero_loaded = false;
+    g->cfg.cur_hash_idx = 0;            // lib.rs:66
+    g->results.clear();
+    return HSW_OK;
+}
+
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) {
     if (!g) return HSW_ERR_INVALID_ARG;
     g->ctx->position(cell, column, row);

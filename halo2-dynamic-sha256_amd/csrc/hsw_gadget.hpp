@@ -64,7 +64,8 @@ class Sha256DynamicConfig {
     size_t cur_hash_idx = 0;                       // lib.rs:43
     uint32_t num_bits_lookup = 8;                  // SpreadConfig (spread.rs:24-25)
     uint32_t num_advice_columns = 2;
-    bool is_input_range_check = false;             // lib.rs:44 (the 8-bit range checks are halo2-base cells: not emitted)
+    bool is_input_range_check = false;             // lib.rs:44 (the 8-bit range checks are halo2-base cells: emitted
+                                                   // by whole-digest contexts only)
 
     // lib.rs:49-69.  HSW_ERR_SHAPE if a size is not a multiple of 64 (lib.rs:57-59)
     // or the spread shape is invalid (spread.rs:37).

@@ -91,6 +91,12 @@ class Sha256DynamicConfig:
         self._ok(self.lib.hsw_gadget_set_columns(self.h, max_rows, C.byref(n)))
         return int(n.value)
 
+    def reset(self):
+        """Next synthesis pass: all cursors back to their start, buffers and layout kept
+        (the reference clones the config per synthesis, lib.rs:440)."""
+        self._ok(self.lib.hsw_gadget_reset(self.h))
+        self._n = 0
+
     def cell_position(self, cell):
         c, r = C.c_uint64(), C.c_uint64()
         self._ok(self.lib.hsw_gadget_cell_position(self.h, cell, C.byref(c), C.byref(r)))

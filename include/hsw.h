@@ -29,6 +29,9 @@
  * One cell = 32 bytes = one BN254 scalar-field element, 4 little-endian 64-bit
  * limbs, canonical (HSW_REPR_CANONICAL) or Montgomery (HSW_REPR_MONTGOMERY,
  * the in-memory form of halo2curves' Fr) form; both are built.
+ * Beyond the block loop: in HSW_MODE_HALO2_INTERNALS the engine also emits the
+ * cells halo2-base / digest() allocate around it ("placement adaptor", "digest
+ * frame" below), up to the literal advice-column image of the whole region.
  *
  * All entry points return an int status (HSW_OK = 0); nothing unwinds across
  * the ABI.  Shape violations that the reference would `assert!`/`debug_assert!`
@@ -387,6 +390,11 @@ void hsw_gadget_destroy(hsw_gadget *g);
  * layout depends only on max_variable_byte_sizes, never on the messages.
  * HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns. */
 int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns);
+/* Start the next synthesis pass with the same buffers and layout: every cursor back to
+ * its initial value (cur_hash_idx, num_limb_sum, the stream cursors, the Context's zero
+ * cell).  What the reference's harnesses do by cloning the config per synthesis
+ * (lib.rs:440, benches/digest.rs:78).  Waits for outstanding work on the engine. */
+int hsw_gadget_reset(hsw_gadget *g);
 /* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);
 /* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.

@@ -223,3 +223,23 @@ def test_set_columns_errors(hsw, eng_int):
         cfg.set_columns(69348 + 16)                # > HSW_MAX_BREAKS + 1 columns
     assert cfg.set_columns(1 << 20) == 3
     cfg.close()
+
+
+def test_gadget_reset_is_a_new_synthesis_pass(hsw, oracle, eng_int):
+    """lib.rs:440 / benches/digest.rs:78: the harnesses clone the config per synthesis to reset
+    cur_hash_idx and the SpreadConfig cursors; hsw_gadget_reset does that on the same buffers."""
+    cfg = hsw.Sha256DynamicConfig(eng_int, [128, 64], is_input_range_check=True, whole_digest=True)
+    cfg.set_columns(150000)
+    cfg.digest_batch([b"first pass", b"x"], [None, None])
+    a = cfg.streams()
+    cfg.reset()
+    assert cfg.view().cur_hash_idx == 0 and cfg.view().num_limb_sum == 0 and cfg.view().gate_cells == 0
+    res = cfg.digest_batch([b"second pass, other data", b"y"], [None, None])
+    b = cfg.streams()
+    ref = oracle.digest_cells([b"second pass, other data", b"y"], [128, 64], None, True)
+    img, _ = _model_columns(ref["call_lens"], ref["gate"], 150000)
+    assert np.array_equal(b["gate"], img) and not np.array_equal(a["gate"], b["gate"])
+    assert np.array_equal(b["lookup"], ref["lookup"])
+    assert np.array_equal(b["dense"], ref["dense"][:, : b["rows"]])
+    assert res[0].output_bytes == hashlib.sha256(b"second pass, other data").digest()
+    cfg.close()
