@@ -109,12 +109,13 @@ int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSucc
 int choose_tile(const hsw_engine *e, uint32_t flags) {
     if (e->limbs != 2) return 32;                 // other tile shapes are built for the 8-bit table only
     if (e->tile > 0) return e->tile;
-    if (flags & HSW_REPR_COMPACT64) return 6416;  // [16 rows][64 cells]: not HBM-bound, wants many small waves
+    if (flags & HSW_REPR_COMPACT64)               // [16 rows][64 cells]: not HBM-bound, wants many small waves
+        return e->mode == HSW_MODE_HALO2_INTERNALS ? 32 : 6416;
     return (flags & HSW_REPR_MONTGOMERY) ? 128 : 64;
 }
 int choose_parts(const hsw_engine *e, size_t n_blocks, int tile, uint32_t flags = 0) {
     // a T-cell tile has 64*32/T rows: [64][32] [32][64] [16][128]; experimental codes TTRR: [32][32] [16][32] [16][64]
-    const int min_parts = tile == 3232 ? 2 : (tile == 3216 || tile == 6416) ? 4 : tile / 32;
+    const int min_parts = tile == 6416 ? 4 : tile / 32;
     if (e->parts > 0) return e->parts < min_parts ? min_parts : e->parts;
     int parts = (flags & HSW_REPR_COMPACT64) ? 8 : ((tile >= 64 && tile < 1000) ? 4 : min_parts);
     if (parts < min_parts) parts = min_parts;
@@ -308,7 +309,7 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         return HSW_OK;
     }
     if (std::strcmp(name, "tile") == 0) {
-        if (value != 0 && value != 32 && value != 64 && value != 128 && value != 3232 && value != 3216 && value != 6416)
+        if (value != 0 && value != 32 && value != 64 && value != 128 && value != 6416)
             return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 0 (auto), 32, 64 or 128");
         e->tile = (int)value;
         return HSW_OK;

@@ -186,8 +186,13 @@ struct Em {
     static constexpr bool MONT = REPR_ == 1;
     static constexpr bool COMPACT = REPR_ == 2;
     static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
-    u64 *row;          // this lane's tile row (LDS)
-    const u64 *tile;   // tile base (LDS)
+    static constexpr int STRIDE = T + 3;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
+    u64 *row0;         // this lane's tile row (LDS), column 0
+    u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
+    u32 carry_neg;     // bit j: carried column j holds a field negation
+    u64 *head;         // [R][3] (LDS): the first 4 - skew cells of every unit, held back until the last flush
+    u64 *row;          // row0 + skew: where cell POS of the current tile goes
+    u64 *tile;         // tile base (LDS)
     u16 *d16;          // staged dense inputs of spread() calls (LDS)
     uint4 *out;        // this block's gate stream, in 16-byte pieces
     u32 nrows;         // units (rows) of the current phase-part
@@ -233,37 +238,73 @@ DEV u32 packed_cell(const EM &em, u32 cl) {       // FlexGate column packing: ad
 DEV void store16(char *base, u32 byte_off, uint4 v) { *reinterpret_cast<uint4 *>(base + (size_t)byte_off) = v; }
 DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base + (size_t)byte_off) = v; }
 
+// Realignment.  HBM writes run at full rate only when every contiguous run covers whole
+// 128-byte lines (measured: a stream starting 32 / 64 / 96 bytes past a line boundary runs
+// 47 / 26 / 47 % slower, tools/align_probe.py) -- but where a block's stream starts is dictated
+// by the circuit layout (digest frames, column breaks, odd max_rows).  So a unit that starts
+// `skew` cells past a line boundary keeps its tile in LDS columns [skew, skew + T): a flush
+// writes columns [0, T) -- a line-aligned window of the stream -- and carries the last `skew`
+// cells over into columns [0, skew) of the next tile.  Only the first and last few cells of a
+// unit are partial lines, and those meet the neighbouring unit's in L2 within the same flush.
 template <class EM, bool FULL>
-DEV void flush_tile(const EM &em, u32 ncells, u32 seg, int na, int nb, int nc, int nd) {
+DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) {
     constexpr int T = EM::TILE;
-    __syncthreads();
+    constexpr int S = EM::STRIDE;
     const u32 lane = threadIdx.x;
     char *base = reinterpret_cast<char *>(em.out);
     const bool packed = em.brk1 != 0xffffffffu;          // wave-uniform; false unless a pack plan is in force
-    if (em.write_gate) {
+    const u32 skew = em.skew;
+    // A skewed unit shares its first line with the previous unit's tail, which is written at the END of
+    // the phase: the first 4 - skew cells of every unit but the wave's first are held back in em.head and
+    // appended to the previous row's tail in the last flush, so that the shared line is completed within
+    // one flush (a partial line costs a read-modify-write in HBM, and in a write-only stream the bus
+    // turnaround of that read is worth ~10 lines).
+    const bool hold_heads = FULL && fl == 0 && skew != 0u;
+    const u32 hc = (!FULL && fl != 0 && skew != 0u) ? 4u - skew : 0u;    // head cells appended per row now
+    const u32 hi = FULL ? (u32)T : ncells + skew;        // one past the last tile column written now
+    if (hold_heads && lane >= 1u && lane < em.nrows)
+        for (u32 j = skew; j < 4u; j++) em.head[lane * 3u + j - skew] = em.row0[j];
+    if (hc != 0u && lane >= 1u && lane < em.nrows)       // memory after row r's tail is row r+1's head
+        for (u32 j = 0; j < hc; j++) em.tile[(lane - 1u) * S + hi + j] = em.head[lane * 3u + j];
+    __syncthreads();
+    const u32 lo0 = fl == 0 ? skew : 0u;                 // first LDS column written now: row 0 ...
+    const u32 lo = hold_heads ? 4u : lo0;                // ... and the other rows
+    const u32 seg = (u32)fl * (u32)T - skew;             // column c holds unit cell seg + c (never used below lo)
+    const u32 cneg = em.carry_neg;
+    // is LDS column p a field negation?  tile position = p - skew; carried columns: bit mask
+    auto is_neg = [&](u32 p) -> bool {
+        if (p < skew) return fl != 0 && ((cneg >> p) & 1u);
+        const u32 q = p - skew;
+        return na >= 0 && (q == (u32)na || q == (u32)nb || q == (u32)nc || q == (u32)nd);
+    };
+    const bool any_neg = na >= 0 || cneg != 0u;
+    if (em.write_gate && hi + hc > lo0) {
+        // partial flushes: every row writes columns [lo0, hi + hc), the last row only [lo0, hi)
+        const u32 ncols = hi + hc - lo0;
+        const u32 total_cells = em.nrows * ncols - hc;
         if constexpr (EM::COMPACT) {
             // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
-            // Negation cells keep x (their positions are static: hsw_neg_cells).
-            (void)na; (void)nb; (void)nc; (void)nd;
-            const u32 total = em.nrows * ncells;
+            // Negation cells keep x (their positions are static: hsw_neg_cells).  (skew is always 0 here)
 #pragma unroll 4
-            for (u32 i = lane; i < total; i += 64) {
-                const u32 r = FULL ? i / (u32)T : i / ncells;
-                const u32 p = FULL ? i % (u32)T : i - r * ncells;
+            for (u32 i = lane; i < total_cells; i += 64) {
+                const u32 r = i / ncols;
+                const u32 p = lo0 + i - r * ncols;
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
                 if (packed) cl = packed_cell(em, cl);
-                store8(base, cl * 8u, em.tile[r * (T + 1) + p]);
+                store8(base, cl * 8u, em.tile[r * S + p]);
             }
         } else if constexpr (EM::MONT) {
-            const u32 total = em.nrows * ncells;
+            // full tiles index by the compile-time T (a shift) and skip the < 4 empty / held-back columns
+            // of a skewed unit's first tile; partial ones divide by the run length
+            const u32 total = FULL ? em.nrows * (u32)T : total_cells;
             for (u32 i = lane; i < total; i += 64) {
-                const u32 r = FULL ? i / (u32)T : i / ncells;
-                const u32 p = FULL ? i % (u32)T : i - r * ncells;
-                const u64 v = em.tile[r * (T + 1) + p];
+                const u32 r = FULL ? i / (u32)T : i / ncols;
+                const u32 p = FULL ? i % (u32)T : lo0 + i - r * ncols;
+                if (FULL && p < (r == 0u ? lo0 : lo)) continue;
+                const u64 v = em.tile[r * S + p];
                 Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
-                if (na >= 0) {                        // compile-time: most tiles hold no neg cell
-                    const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
-                    if (isneg && v != 0ull) m = fe_neg_nonzero(m);
+                if (any_neg) {                        // compile-time false for most tiles
+                    if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
                 }
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
                 if (packed) cl = packed_cell(em, cl);
@@ -272,49 +313,60 @@ DEV void flush_tile(const EM &em, u32 ncells, u32 seg, int na, int nb, int nc, i
             }
         } else if (FULL && !packed) {
             // the common case: a full tile, no column break in this block.  Lane l owns the
-            // 16-byte piece (l & 1) of cell (l >> 1) + 32 k of every row; LDS and HBM
+            // 16-byte piece (l & 1) of LDS column (l >> 1) + 32 k of every row; LDS and HBM
             // addresses advance by constants.
             const u32 h = lane & 1u, p0 = lane >> 1;
             const u64 *src = em.tile + p0;
             u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
             const u32 row_bytes = em.unit_cells * 32u;
-            for (u32 r = 0; r < em.nrows; r++, src += T + 1, off += row_bytes) {
+            for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+                const bool skip0 = p0 < (r == 0u ? lo0 : lo);   // first tile of a skewed unit
 #pragma unroll
                 for (int k = 0; k < T / 32; k++) {
                     const u64 v = src[32 * k];
-                    const u32 lo = (u32)v, hi = (u32)(v >> 32);
-                    uint4 o = make_uint4(h ? 0u : lo, h ? 0u : hi, 0u, 0u);
-                    if (na >= 0) {
-                        const u32 p = p0 + 32u * (u32)k;
-                        const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
-                        if (isneg && v != 0ull)       // cell holds p - x (neg gate, compression.rs:320-321)
+                    const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+                    uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
+                    if (any_neg) {
+                        if (is_neg(p0 + 32u * (u32)k) && v != 0ull)   // cell holds p - x (neg gate, compression.rs:320-321)
                             o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
-                                  : make_uint4(HSW_P0 - lo, HSW_P1, HSW_P2, HSW_P3);
+                                  : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                     }
-                    store16(base, off + 1024u * (u32)k, o);
+                    if (k != 0 || !skip0) store16(base, off + 1024u * (u32)k, o);
                 }
             }
         } else {
-            const u32 ppr = 2u * ncells;          // 16-byte pieces per row
-            const u32 total = em.nrows * ppr;
+            // (a FULL flush that lands here -- a column break in this block -- has hc = 0)
+            const u32 ppr = 2u * ncols;           // 16-byte pieces per row
+            const u32 total = 2u * total_cells;
             for (u32 i = lane; i < total; i += 64) {
                 const u32 r = i / ppr;
                 const u32 q = i - r * ppr;
-                const u32 p = q >> 1, h = q & 1u;
-                const u64 v = em.tile[r * (T + 1) + p];
-                const u32 lo = (u32)v, hi = (u32)(v >> 32);
-                uint4 o = make_uint4(h ? 0u : lo, h ? 0u : hi, 0u, 0u);
-                if (na >= 0) {
-                    const bool isneg = p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd;
-                    if (isneg && v != 0ull)
+                const u32 p = lo0 + (q >> 1), h = q & 1u;
+                if (FULL && p < lo && r != 0u) continue;
+                const u64 v = em.tile[r * S + p];
+                const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+                uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
+                if (any_neg) {
+                    if (is_neg(p) && v != 0ull)
                         o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
-                              : make_uint4(HSW_P0 - lo, HSW_P1, HSW_P2, HSW_P3);
+                              : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                 }
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
                 if (packed) cl = packed_cell(em, cl);
                 store16(base, cl * 32u + h * 16u, o);
             }
         }
+    }
+    if (FULL && skew != 0u) {
+        // carry the last `skew` cells (LDS columns [T, T + skew)) over to columns [0, skew)
+        __syncthreads();                                 // every lane's stores have read the tile
+        u32 m = 0;
+        for (u32 j = 0; j < skew; j++) {
+            em.row0[j] = em.row0[T + j];
+            const u32 q = (u32)T + j - skew;             // tile position of the carried cell
+            if (na >= 0 && (q == (u32)na || q == (u32)nb || q == (u32)nc || q == (u32)nd)) m |= 1u << j;
+        }
+        em.carry_neg = (u32)__builtin_amdgcn_readfirstlane((int)m);     // wave-uniform: keep it scalar
     }
     __syncthreads();
 }
@@ -323,7 +375,7 @@ template <class EM, class C>
 DEV auto emit(C, EM &em, u64 v) {
     em.row[C::pos] = v;
     if constexpr (C::pos + 1 == EM::TILE) {
-        flush_tile<EM, true>(em, EM::TILE, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
+        flush_tile<EM, true>(em, EM::TILE, C::fl, C::na, C::nb, C::nc, C::nd);
         return Cur<0, C::fl + 1>{};
     } else {
         return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd>{};
@@ -375,6 +427,19 @@ DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u
     em.lk = r * lk_per_unit;
     em.lk_first = lk_base + unit_lo * lk_per_unit;
     em.lks = nrows * lk_per_unit;
+    // realignment (flush_tile): only where every unit of the phase starts at the same offset within
+    // a 128-byte line (unit_cells % 4 == 0: words, schedule steps, rounds -- 98 % of the cells)
+    u32 skew = 0;
+    if constexpr (!EM::COMPACT) {
+        if ((unit_cells & 3u) == 0u) {
+            u32 cl = em.cell_base;
+            if (em.brk1 != 0xffffffffu) cl = packed_cell(em, cl);
+            skew = (cl + (u32)(reinterpret_cast<size_t>(em.out) >> 5)) & 3u;
+        }
+    }
+    em.skew = (u32)__builtin_amdgcn_readfirstlane((int)skew);           // wave-uniform: keep it scalar
+    em.carry_neg = 0;
+    em.row = em.row0 + skew;
     return nrows != 0;
 }
 
@@ -468,7 +533,8 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
 
 template <int L, class EM, class C>
 DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
-    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl * EM::TILE, C::na, C::nb, C::nc, C::nd);
+    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd);
+    else if (em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1);      // the carried cells only
     flush_chip<L>(em, p, block_first_limb);
     if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
 }
@@ -768,15 +834,16 @@ DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
 template <int L, int T, int R, int REPR, bool RC>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     using LY = Lay<L, RC>;
-    static_assert(R * (T + 1) * 8 >= 800, "tile must be able to hold the chain seeds");
+    static_assert(R * (T + 3) * 8 >= 800, "tile must be able to hold the chain seeds");
     // The chain seeds live in LDS only until every lane has pulled its own into
     // registers; the tile then reuses the same bytes (keeps the workgroup at
     // <= 20 KiB of LDS = 8 waves per CU, so 4,096 blocks are exactly 2 waves of
     // residency on 256 CUs).
-    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * (T + 1)];   // +1 scratch row for lanes >= R
+    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * (T + 3)];   // +1 scratch row for lanes >= R; +3 carry columns
     u32 *sW = reinterpret_cast<u32 *>(s_tile);   // [64]
     u32 *sA = sW + 64;         // [68] sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
     u32 *sE = sA + 68;         // [68] sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
+    __shared__ u64 s_head[R * 3];                 // realignment: held-back first cells of every unit (flush_tile)
     __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
     __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
 
@@ -843,7 +910,11 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     EM em;
     em.lk16 = s_lk16;
     em.tile = s_tile;
-    em.row = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 1);   // lanes >= R never flush: scratch row
+    em.row0 = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 3);   // lanes >= R never flush: scratch row
+    em.row = em.row0;
+    em.skew = 0;
+    em.carry_neg = 0;
+    em.head = s_head;
     em.d16 = s_d16;
     {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
         u64 first = (u64)blk * (u64)LY::GATE_CELLS;
@@ -966,13 +1037,16 @@ template <int L>
 hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
     if (p.flags & HSW_K_INTERNALS) {
-        // halo2-base internals (A3) are built for the reference's 8-bit table only, 32-cell tiles
-        if constexpr (L == 2) return launch_expand_LTR<L, 32, 64, true>(p, stream);
-        else return hipErrorInvalidValue;
+        // halo2-base internals (A3) are built for the reference's 8-bit table only
+        if constexpr (L == 2) {
+            switch (tile) {
+                case 64: return launch_expand_LTR<L, 64, 32, true>(p, stream);
+                case 128: return launch_expand_LTR<L, 128, 16, true>(p, stream);
+                default: return launch_expand_LTR<L, 32, 64, true>(p, stream);
+            }
+        } else return hipErrorInvalidValue;
     }
     switch (tile) {
-        case 3232: if constexpr (L == 2) return launch_expand_LTR<L, 32, 32, false>(p, stream); else return hipErrorInvalidValue;
-        case 3216: if constexpr (L == 2) return launch_expand_LTR<L, 32, 16, false>(p, stream); else return hipErrorInvalidValue;
         case 6416: if constexpr (L == 2) return launch_expand_LTR<L, 64, 16, false>(p, stream); else return hipErrorInvalidValue;
         case 32: return launch_expand_LTR<L, 32, 64, false>(p, stream);
         case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32, false>(p, stream); else return hipErrorInvalidValue;

@@ -423,7 +423,7 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
 /* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
  * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
  * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
- * (also the experimental shapes 3232, 3216, 6416 = [rows][cells] 32x32, 16x32, 16x64). */
+ * (also 6416 = [16 rows][64 cells], the default of the compact form). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 
 const char *hsw_strerror(int status);

@@ -48,6 +48,39 @@ def test_internals_stream_and_lookup_column(eng_int, oracle, hsw, mont):
     assert (ref["lookup"][:, 0] < 65536).all() and not ref["lookup"][:, 1:].any()
 
 
+@pytest.mark.parametrize("tile,parts", [(32, 1), (32, 8), (64, 2), (64, 4), (128, 4), (128, 16), (0, 0)])
+@pytest.mark.parametrize("flags_name", ["canonical", "montgomery", "compact"])
+def test_internals_every_tile_shape(eng_int, oracle, hsw, tile, parts, flags_name):
+    """The internals kernels are built for the same three tile shapes as the default mode."""
+    import torch
+    N = hsw._native
+    flags = {"canonical": 0, "montgomery": N.HSW_REPR_MONTGOMERY, "compact": N.HSW_REPR_COMPACT64}[flags_name]
+    eng_int.set_option("tile", tile)
+    eng_int.set_option("parts", parts)
+    try:
+        blocks, pre = _inputs(3, 1000 + tile + parts)
+        ref = oracle.Oracle(8, 2, check=True, internals=True).witness_blocks(blocks, pre, cursor0=5)
+        out = eng_int.witness_blocks_ex(torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda(),
+                                        cursor0=5, want_lookup=True, flags=flags)
+        eng_int.synchronize()
+        if flags_name == "compact":
+            g = out["gate"].cpu().numpy().view(np.uint64).reshape(-1)[: 3 * eng_int.G]
+            exp = ref["gate"][:, 0].copy()
+            neg = np.nonzero(ref["gate"][:, 1:].any(axis=1))[0]
+            exp[neg] = np.uint64(0x43e1f593f0000001) - exp[neg]          # the cell holds x where the value is p - x
+            assert np.array_equal(g, exp)
+            lk = out["lookup"].cpu().numpy().view(np.uint64).reshape(-1)[: 3 * eng_int.lookup_cells]
+            assert np.array_equal(lk, ref["lookup"][:, 0])
+        else:
+            conv = oracle.to_montgomery if flags_name == "montgomery" else (lambda x: x)
+            assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), conv(ref["gate"]))
+            assert np.array_equal(out["lookup"].cpu().numpy().view(np.uint64), conv(ref["lookup"]))
+            assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), conv(ref["dense"]))
+    finally:
+        eng_int.set_option("tile", 0)
+        eng_int.set_option("parts", 0)
+
+
 @pytest.mark.parametrize("parts", [1, 4, 16])
 def test_internals_with_split_blocks(eng_int, oracle, parts):
     import torch

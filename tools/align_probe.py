@@ -26,7 +26,7 @@ def run(off):
         if i >= 2:
             ms.append(eng.last_kernel_ms())
     return float(np.median(ms))
-offs = [0, 256, 4096, 65536, 1 << 20, 2 << 20, (2 << 20) + 4096, 1 << 30, (1 << 30) + 12345 * 16, 5 << 30, 10 << 30, 13 << 30]
+offs = [0, 32, 64, 96, 128, 160, 256, 4096, 65536, 1 << 20, 2 << 20, (2 << 20) + 4096, 1 << 30, (1 << 30) + 12345 * 16, 5 << 30, 10 << 30, 13 << 30]
 for rep in range(2):
     for off in offs:
         print(json.dumps({"offset": off, "ms": round(run(off), 4)}), flush=True)
