@@ -158,11 +158,11 @@ int hsw_engine_synchronize(hsw_engine *e);
  *   d_pre_states  n*8 u32 pre-state words       (device memory)
  *   spread_cursor0  SpreadConfig.num_limb_sum before the first block
  *                 (spread.rs:26,202); block j starts at cursor0 + j*limb_calls_per_block
- *   d_gate        n*G cells (device memory); must be 16-byte aligned, should be
- *                 32-byte aligned: at 16 mod 32 every canonical cell straddles
- *                 two 32-byte sectors and the launch runs ~45 % slower
- *                 (tools/align_probe.py); beyond that placement moves the rate
- *                 by +-3 % only
+ *   d_gate        n*G cells (device memory); must be 16-byte aligned and should be
+ *                 32-byte (cell) aligned: at 16 mod 32 every canonical cell straddles
+ *                 two sectors and the launch runs ~45 % slower.  Any cell-aligned
+ *                 position is fine -- the kernel realigns its write-out to 128-byte
+ *                 lines (a few % slower than a line-aligned stream)
  *   d_chip_dense / d_chip_spread
  *                 ncols columns each; column c starts at base + c*chip_col_stride
  *                 cells; hsw_chip_rows() rows are written per column (cells of
