@@ -11,7 +11,7 @@ class AssignedHashResult:
 
     def __init__(self, r, input_bytes):
         self.input_len = int(r.input_len)
-        self.input_bytes = input_bytes
+        self._input_bytes = input_bytes          # bytes, or a callable fetching them on first use
         self.output_bytes = bytes(r.output_bytes)
         self.first_block = int(r.first_block)
         self.n_blocks = int(r.n_blocks)
@@ -22,6 +22,14 @@ class AssignedHashResult:
         for k in ("prologue_cell", "block_cell", "epilogue_cell", "end_cell",
                   "prologue_lookup", "block_lookup", "epilogue_lookup"):
             setattr(self, k, int(getattr(r, k)))
+
+
+    @property
+    def input_bytes(self):
+        """assigned_input_bytes (lib.rs:170-173): the padded variable part, max_variable_byte_size bytes."""
+        if callable(self._input_bytes):
+            self._input_bytes = self._input_bytes()
+        return self._input_bytes
 
 
 class Sha256DynamicConfig:
@@ -80,7 +88,8 @@ class Sha256DynamicConfig:
         pre = (C.c_size_t * n)(*[int(p or 0) for p in pl])
         res = (N.HashResult * n)()
         self._ok(self.lib.hsw_gadget_digest_batch(self.h, n, ptrs, lens, pre, res))
-        out = [AssignedHashResult(res[i], self._input_bytes(self._n + i)) for i in range(n)]
+        base = self._n
+        out = [AssignedHashResult(res[i], (lambda k=base + i: self._input_bytes(k))) for i in range(n)]
         self._n += n
         return out
 
