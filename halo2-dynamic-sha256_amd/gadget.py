@@ -51,9 +51,16 @@ class Sha256DynamicConfig:
             raise N.HswError(rc, self.lib.hsw_last_error(engine.h).decode())
         self.h = h
         self._n = 0
+        self._pending = []      # results whose input_bytes have not been fetched yet
+
+    def _resolve_pending(self):
+        for r in self._pending:
+            r.input_bytes               # fetch while the gadget still holds them
+        self._pending = []
 
     def close(self):
         if getattr(self, "h", None):
+            self._resolve_pending()
             self.lib.hsw_gadget_destroy(self.h)
             self.h = None
 
@@ -91,6 +98,7 @@ class Sha256DynamicConfig:
         base = self._n
         out = [AssignedHashResult(res[i], (lambda k=base + i: self._input_bytes(k))) for i in range(n)]
         self._n += n
+        self._pending.extend(out)
         return out
 
     def set_columns(self, max_rows):
@@ -103,6 +111,7 @@ class Sha256DynamicConfig:
     def reset(self):
         """Next synthesis pass: all cursors back to their start, buffers and layout kept
         (the reference clones the config per synthesis, lib.rs:440)."""
+        self._resolve_pending()
         self._ok(self.lib.hsw_gadget_reset(self.h))
         self._n = 0
 

@@ -243,3 +243,43 @@ def test_gadget_reset_is_a_new_synthesis_pass(hsw, oracle, eng_int):
     assert np.array_equal(b["dense"], ref["dense"][:, : b["rows"]])
     assert res[0].output_bytes == hashlib.sha256(b"second pass, other data").digest()
     cfg.close()
+
+
+def test_whole_digest_randomized_contexts(hsw, oracle, eng_int):
+    """Random contexts: 1-4 digests of random maximum sizes, message lengths up to the maximum,
+    random precomputed prefixes, both range-check settings, batched or one by one, optionally as a
+    column image with a random max_rows -- always bit-exact against the oracle."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(14):
+        k = int(rng.integers(1, 5))
+        sizes, msgs, pres = [], [], []
+        for _ in range(k):
+            nb = int(rng.integers(1, 5))
+            pre_rounds = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+            # total padded rounds must satisfy pre_rounds <= num_round <= pre_rounds + nb
+            num_round = int(rng.integers(max(pre_rounds, 1), pre_rounds + nb + 1))
+            ln = int(rng.integers(max(0, 64 * (num_round - 1) - 8), 64 * num_round - 8))   # ceil((ln+9)/64) == num_round
+            sizes.append(64 * nb)
+            msgs.append(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+            pres.append(64 * pre_rounds)
+        rc = bool(rng.integers(0, 2))
+        batch = bool(rng.integers(0, 2))
+        max_rows = int(rng.integers(69348 + 16, 200000)) if rng.random() < 0.5 else None
+        cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=rc, whole_digest=True)
+        try:
+            if max_rows is not None:
+                try:
+                    cfg.set_columns(max_rows)
+                except hsw.HswError:
+                    max_rows = None                      # > 17 columns: keep the linear stream
+            res = cfg.digest_batch(msgs, pres) if batch else [cfg.digest(m, p) for m, p in zip(msgs, pres)]
+            st = cfg.streams()
+        finally:
+            cfg.close()
+        ref = oracle.digest_cells(msgs, sizes, pres, rc)
+        for m, r in zip(msgs, res):
+            assert r.output_bytes == hashlib.sha256(m).digest(), (trial, len(m))
+        exp = _model_columns(ref["call_lens"], ref["gate"], max_rows)[0] if max_rows else ref["gate"]
+        assert np.array_equal(st["gate"], exp), (trial, sizes, [len(m) for m in msgs], pres, rc, batch, max_rows)
+        assert np.array_equal(st["lookup"], ref["lookup"]), trial
+        assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]]), trial
