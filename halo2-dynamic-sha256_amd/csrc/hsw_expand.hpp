@@ -217,10 +217,13 @@ struct Em {
 // Compile-time emission cursor: POS = cells already in the current tile, FL =
 // tiles flushed so far in this phase, NA..ND = the (at most four: ch has four per
 // round, compression.rs:320-335) tile positions holding a field negation, -1 = none.
-template <int POS, int FL, int NA = -1, int NB = -1, int NC = -1, int ND = -1>
+// CN: the previous tile had a negation among its last three positions, i.e. one may have been carried
+// into this tile by the realigning flush (only then does the flush look at the runtime carry mask).
+template <int POS, int FL, int NA = -1, int NB = -1, int NC = -1, int ND = -1, bool CN = false>
 struct Cur {
     static constexpr int pos = POS, fl = FL;
     static constexpr int na = NA, nb = NB, nc = NC, nd = ND;
+    static constexpr bool cn = CN;
 };
 using CurStart = Cur<0, 0>;
 
@@ -247,7 +250,7 @@ DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base
 // cells over into columns [0, skew) of the next tile.  Only the first and last few cells of a
 // unit are partial lines, and those meet the neighbouring unit's in L2 within the same flush.
 template <class EM, bool FULL>
-DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) {
+DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, bool cn) {
     constexpr int T = EM::TILE;
     constexpr int S = EM::STRIDE;
     const u32 lane = threadIdx.x;
@@ -270,24 +273,34 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) 
     const u32 lo0 = fl == 0 ? skew : 0u;                 // first LDS column written now: row 0 ...
     const u32 lo = hold_heads ? 4u : lo0;                // ... and the other rows
     const u32 seg = (u32)fl * (u32)T - skew;             // column c holds unit cell seg + c (never used below lo)
-    const u32 cneg = em.carry_neg;
+    const u32 cneg = cn ? em.carry_neg : 0u;             // cn is a compile-time constant at every call site
     // is LDS column p a field negation?  tile position = p - skew; carried columns: bit mask
     auto is_neg = [&](u32 p) -> bool {
+        if (skew == 0u)                                  // wave-uniform: the aligned case stays 4 compares
+            return na >= 0 && (p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd);
         if (p < skew) return fl != 0 && ((cneg >> p) & 1u);
         const u32 q = p - skew;
         return na >= 0 && (q == (u32)na || q == (u32)nb || q == (u32)nc || q == (u32)nd);
     };
     const bool any_neg = na >= 0 || cneg != 0u;
+    const bool first_skewed = FULL && fl == 0 && skew != 0u;      // wave-uniform: some leading columns are not written
     if (em.write_gate && hi + hc > lo0) {
         // partial flushes: every row writes columns [lo0, hi + hc), the last row only [lo0, hi)
         const u32 ncols = hi + hc - lo0;
         const u32 total_cells = em.nrows * ncols - hc;
+        // a partial flush writes ncells columns per row, or ncells + 4 when skewed (skew carried + 4 - skew
+        // appended): both are compile-time constants after inlining, so the row of piece i is two
+        // divisions by constants and a select instead of a runtime division
+        const bool wide_rows = hc != 0u;
+        auto row_of = [&](u32 i, u32 per_cell) -> u32 {
+            return wide_rows ? i / ((ncells + 4u) * per_cell) : i / ((ncells ? ncells : 1u) * per_cell);
+        };
         if constexpr (EM::COMPACT) {
             // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
             // Negation cells keep x (their positions are static: hsw_neg_cells).  (skew is always 0 here)
 #pragma unroll 4
             for (u32 i = lane; i < total_cells; i += 64) {
-                const u32 r = i / ncols;
+                const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = lo0 + i - r * ncols;
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
                 if (packed) cl = packed_cell(em, cl);
@@ -298,9 +311,9 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) 
             // of a skewed unit's first tile; partial ones divide by the run length
             const u32 total = FULL ? em.nrows * (u32)T : total_cells;
             for (u32 i = lane; i < total; i += 64) {
-                const u32 r = FULL ? i / (u32)T : i / ncols;
+                const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = FULL ? i % (u32)T : lo0 + i - r * ncols;
-                if (FULL && p < (r == 0u ? lo0 : lo)) continue;
+                if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
                 const u64 v = em.tile[r * S + p];
                 Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
                 if (any_neg) {                        // compile-time false for most tiles
@@ -320,7 +333,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) 
             u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
             const u32 row_bytes = em.unit_cells * 32u;
             for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
-                const bool skip0 = p0 < (r == 0u ? lo0 : lo);   // first tile of a skewed unit
+                const bool skip0 = first_skewed && p0 < (r == 0u ? lo0 : lo);
 #pragma unroll
                 for (int k = 0; k < T / 32; k++) {
                     const u64 v = src[32 * k];
@@ -335,14 +348,15 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd) 
                 }
             }
         } else {
-            // (a FULL flush that lands here -- a column break in this block -- has hc = 0)
-            const u32 ppr = 2u * ncols;           // 16-byte pieces per row
-            const u32 total = 2u * total_cells;
+            // (a FULL flush that lands here -- a column break in this block -- walks all T columns and
+            //  skips the empty / held-back ones of a skewed unit's first tile)
+            const u32 ppr = FULL ? 2u * (u32)T : 2u * ncols;        // 16-byte pieces per row
+            const u32 total = FULL ? em.nrows * ppr : 2u * total_cells;
             for (u32 i = lane; i < total; i += 64) {
-                const u32 r = i / ppr;
+                const u32 r = FULL ? i / (2u * (u32)T) : row_of(i, 2u);
                 const u32 q = i - r * ppr;
-                const u32 p = lo0 + (q >> 1), h = q & 1u;
-                if (FULL && p < lo && r != 0u) continue;
+                const u32 p = (FULL ? 0u : lo0) + (q >> 1), h = q & 1u;
+                if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
                 const u64 v = em.tile[r * S + p];
                 const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
                 uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
@@ -375,20 +389,22 @@ template <class EM, class C>
 DEV auto emit(C, EM &em, u64 v) {
     em.row[C::pos] = v;
     if constexpr (C::pos + 1 == EM::TILE) {
-        flush_tile<EM, true>(em, EM::TILE, C::fl, C::na, C::nb, C::nc, C::nd);
-        return Cur<0, C::fl + 1>{};
+        flush_tile<EM, true>(em, EM::TILE, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+        constexpr int T3 = EM::TILE - 3;
+        constexpr bool carried = C::na >= T3 || C::nb >= T3 || C::nc >= T3 || C::nd >= T3;
+        return Cur<0, C::fl + 1, -1, -1, -1, -1, carried>{};
     } else {
-        return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd>{};
+        return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd, C::cn>{};
     }
 }
 // cell whose field value is -x (x small): stored as x, its position appended to the cursor's neg list
 template <class EM, class C>
 DEV auto emit_neg(C, EM &em, u64 x) {
     static_assert(C::nd < 0, "more than four neg cells in one tile");
-    if constexpr (C::na < 0) return emit(Cur<C::pos, C::fl, C::pos>{}, em, x);
-    else if constexpr (C::nb < 0) return emit(Cur<C::pos, C::fl, C::na, C::pos>{}, em, x);
-    else if constexpr (C::nc < 0) return emit(Cur<C::pos, C::fl, C::na, C::nb, C::pos>{}, em, x);
-    else return emit(Cur<C::pos, C::fl, C::na, C::nb, C::nc, C::pos>{}, em, x);
+    if constexpr (C::na < 0) return emit(Cur<C::pos, C::fl, C::pos, -1, -1, -1, C::cn>{}, em, x);
+    else if constexpr (C::nb < 0) return emit(Cur<C::pos, C::fl, C::na, C::pos, -1, -1, C::cn>{}, em, x);
+    else if constexpr (C::nc < 0) return emit(Cur<C::pos, C::fl, C::na, C::nb, C::pos, -1, C::cn>{}, em, x);
+    else return emit(Cur<C::pos, C::fl, C::na, C::nb, C::nc, C::pos, C::cn>{}, em, x);
 }
 
 // Units of a phase dealt to `parts` waves: part k expands the contiguous range
@@ -533,8 +549,8 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
 
 template <int L, class EM, class C>
 DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
-    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd);
-    else if (em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1);      // the carried cells only
+    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+    else if (em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1, C::cn);      // the carried cells only
     flush_chip<L>(em, p, block_first_limb);
     if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
 }
