@@ -10,9 +10,9 @@ SRC = os.path.join(ROOT, "examples", "digest_abc.c")
 LIBDIR = os.path.join(ROOT, "halo2-dynamic-sha256_amd")
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "digest_abc")
-    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), SRC,
+def _build(tmp_path, src=SRC):
+    exe = str(tmp_path / os.path.splitext(os.path.basename(src))[0])
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), src,
            "-L" + LIBDIR, "-lhsw", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -35,3 +35,21 @@ def test_c_example_runs_reference_flow(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad" in r.stdout
     assert "first gate row: [0, 128, 1, 128]" in r.stdout and r.stdout.strip().endswith("ok")
+
+
+WHOLE = os.path.join(ROOT, "examples", "whole_region.c")
+
+
+def test_whole_region_example_links(tmp_path):
+    _build(tmp_path, WHOLE)
+
+
+@pytest.mark.gpu
+def test_whole_region_example_runs_the_bench_circuit(tmp_path):
+    """benches/digest.rs:103-129 as 9 advice columns + lookup column, from plain C."""
+    import hashlib
+    exe = _build(tmp_path, WHOLE)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "advice columns: 9 x 131063 rows; gate cells 1116315, lookup cells 53059" in r.stdout
+    assert hashlib.sha256(bytes([1] * 56)).hexdigest() in r.stdout and r.stdout.strip().endswith("ok")
