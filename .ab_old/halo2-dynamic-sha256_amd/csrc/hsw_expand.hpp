@@ -1,0 +1,1078 @@
+// hsw_expand.hpp -- gfx950 (MI355X / CDNA4) kernels of the SHA-256 witness engine.
+//
+// One 64-lane wavefront per work item (workgroup = one wave); a block is one
+// work item, or is dealt to 2..16 of them (`parts`).
+//
+//  chain phase   the plain SHA-256 recurrence of the block (W[0..63] and the a/e
+//                value born in every round) is computed once, wave-uniform, and
+//                staged in LDS; every lane then pulls the seeds of ITS units
+//                into registers.  From these seeds every unit of the gadget (a
+//                schedule step, a round, ...) is independent.
+//  expand phase  lane = unit.  Every lane runs the same straight-line program --
+//                the reference's gate-call sequence for that unit
+//                (compression.rs:57-96 for a schedule step, :125-196 for a
+//                round) -- and appends each gate cell to its own row of an
+//                [R][T] LDS tile of 64-bit values.  WHERE a cell goes is a
+//                compile-time cursor type (Cur<POS, FLUSHES, NEG0, NEG1>)
+//                threaded through every gate function, so an emitted cell is
+//                one ds_write_b64 at an immediate offset and each flush point
+//                is an `if constexpr`.  Spread/dense conversions are shift/mask
+//                bit interleaves, no table reads.
+//  write-out     when a tile is full the wave transposes it to HBM: for every
+//                row, lanes store consecutive 16-byte pieces, i.e. each
+//                global_store_dwordx4 wave-instruction writes 1 KiB contiguous
+//                (canonical form).  Montgomery form (x * 2^256 mod p,
+//                halo2curves' in-memory Fr) does one 64x256-bit
+//                multiply + Barrett reduce per cell, one lane per cell.
+//  chip columns  the 16-bit dense input of every SpreadConfig::spread call is
+//                staged in LDS; at the end of each phase the chip columns
+//                denses[c] / spreads[c] (spread.rs:196-233) receive one
+//                contiguous run of rows per column.
+//
+// Pure 32/64-bit integer work, write-streaming: the bound is HBM write
+// bandwidth (DESIGN.md "Roofline").  No MFMA.
+#ifndef HSW_EXPAND_HPP
+#define HSW_EXPAND_HPP
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hsw_kernels.h"
+#include "hsw_layout.h"
+
+namespace hsw {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef unsigned short u16;
+
+// FIPS 180-4 round constants (reference compression.rs:992-1001: K enters the
+// circuit as a gate constant).
+static __constant__ u32 K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static __device__ __constant__ u32 IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                                        0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+// BN254 Fr modulus p, 32-bit little-endian limbs.  -x for 0 < x <= 0x55555555
+// only touches limb 0: p[0] = 0xf0000001 > x, so there is no borrow.
+#define HSW_P0 0xf0000001u
+#define HSW_P1 0x43e1f593u
+#define HSW_P2 0x79b97091u
+#define HSW_P3 0x2833e848u
+#define HSW_P4 0x8181585du
+#define HSW_P5 0xb85045b6u
+#define HSW_P6 0xe131a029u
+#define HSW_P7 0x30644e72u
+
+#define DEV __device__ __forceinline__
+
+DEV u32 rotr32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// dense 16 bits -> 32 bits with bit i at position 2i (the "spread" form,
+// reference spread.rs:211-218 / table rows of :165-194), by shifts and masks.
+DEV u32 spread16(u32 x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+DEV u64 spread32(u32 x) { return (u64)spread16(x) | ((u64)spread16(x >> 16) << 32); }
+// even-position bits of a 32-bit value packed into 16 bits
+// (decompose_even_and_odd_unchecked, spread.rs:146-157; odd = even_bits(x >> 1)).
+DEV u32 even_bits(u32 x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+
+// ---------------------------------------------------------- Montgomery form
+// HSW_REPR_MONTGOMERY: a cell holds x * 2^256 mod p, halo2curves' in-memory Fr.
+// For x = lo + hi*2^32 < 2^64:  x*R mod p = lo*R + hi*R32 (mod p) with the
+// constants R = 2^256 mod p (~0.29 p) and R32 = 2^288 mod p (~0.14 p), so
+// t = lo*R + hi*R32 < 0.43 * 2^32 * p: the quotient fits 32 bits, and one
+// Barrett step with mu = floor(2^288/p) on the top 64 bits of t gives q^ = q or
+// q - 1 (t/p - th*mu/2^64 < 2^-29 + 0.43), i.e. r = t - q^ p < 2p: exactly one
+// conditional subtraction.  32-bit limbs with explicit carry chains
+// (v_addc_co / v_subb_co): the u64 formulation cost 316 instructions per cell,
+// this one ~170.
+struct Fe8 { u32 l[8]; };
+#define HSW_MU 0x54a474626ull      /* floor(2^288 / p) */
+
+template <bool HAS_HI>
+DEV Fe8 mont_from_u64(u32 lo, u32 hi) {
+    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
+    const u32 RR[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,       // 2^256 mod p
+                       0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    const u32 R32[8] = {0x15b8b9dau, 0x93e78865u, 0xb05ea154u, 0x16df2426u,      // 2^288 mod p
+                        0x302ab839u, 0x1271b743u, 0xec6c226eu, 0x06bc037eu};
+    u32 t[9];
+    u32 cy;
+    {   // t = lo * R: low halves at limb j, high halves at limb j + 1
+        u32 h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { t[j] = lo * RR[j]; h[j] = __umulhi(lo, RR[j]); }
+        cy = 0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h[j - 1], cy, &cy);
+        t[8] = h[7] + cy;
+    }
+    if (HAS_HI) {   // t += hi * R32
+        u32 l2[8], h2[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { l2[j] = hi * R32[j]; h2[j] = __umulhi(hi, R32[j]); }
+        cy = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = __builtin_addc(t[j], l2[j], cy, &cy);
+        t[8] += cy;
+        cy = 0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h2[j - 1], cy, &cy);
+        t[8] += h2[7] + cy;
+    }
+    const u64 th = ((u64)t[8] << 32) | t[7];
+    const u32 q = (u32)__umul64hi(th, HSW_MU);            // < 0.43 * 2^32
+    // r = (t - q*p) mod 2^256 (the true value is < 2p < 2^256)
+    u32 ql[8], qh[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ql[j] = q * P[j]; qh[j] = __umulhi(q, P[j]); }
+    Fe8 r;
+    u32 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = __builtin_subc(t[j], ql[j], br, &br);
+    br = 0;
+#pragma unroll
+    for (int j = 1; j < 8; j++) r.l[j] = __builtin_subc(r.l[j], qh[j - 1], br, &br);
+    u32 sub[8];
+    br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sub[j] = __builtin_subc(r.l[j], P[j], br, &br);
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = br ? r.l[j] : sub[j];
+    return r;
+}
+// p - m for a non-zero Montgomery-form m
+DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
+    const u32 P[8] = {HSW_P0, HSW_P1, HSW_P2, HSW_P3, HSW_P4, HSW_P5, HSW_P6, HSW_P7};
+    Fe8 o;
+    u32 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o.l[j] = __builtin_subc(P[j], m.l[j], br, &br);
+    return o;
+}
+
+// ------------------------------------------------------------------ emitter
+// Emission state of one lane.  `row`, `active`, `call`, `unit` are per lane; the
+// rest is wave-uniform.  WHERE a cell goes inside the tile is not state at all:
+// it is the compile-time cursor type below, so every emitted cell is one
+// ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
+// REPR: 0 = canonical 32-byte cells, 1 = Montgomery 32-byte cells, 2 = compact 8-byte cells
+// (low 64 bits; the negation cells hold x where the field value is -x -- hsw.h HSW_REPR_COMPACT64).
+template <int T, int R, int REPR_, bool RC_>
+struct Em {
+    static constexpr int TILE = T, ROWS = R;
+    static constexpr int REPR = REPR_;
+    static constexpr bool MONT = REPR_ == 1;
+    static constexpr bool COMPACT = REPR_ == 2;
+    static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
+    static constexpr int STRIDE = T + 3;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
+    u64 *row0;         // this lane's tile row (LDS), column 0
+    u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
+    u32 carry_neg;     // bit j: carried column j holds a field negation
+    u64 *head;         // [R][3] (LDS): the first 4 - skew cells of every unit, held back until the last flush
+    u64 *row;          // row0 + skew: where cell POS of the current tile goes
+    u64 *tile;         // tile base (LDS)
+    u16 *d16;          // staged dense inputs of spread() calls (LDS)
+    uint4 *out;        // this block's gate stream, in 16-byte pieces
+    u32 nrows;         // units (rows) of the current phase-part
+    u32 unit_cells;    // gate cells per unit
+    u32 cell_base;     // cell index (in block) of the phase-part's first unit, cell 0
+    u32 call;          // this lane's next spread-call slot (index into d16, phase-local)
+    u32 unit;          // the unit (word / schedule step / round ...) this lane expands
+    u32 call_first;    // block-relative index of the phase-part's first spread call
+    u32 calls;         // spread calls staged by this phase-part (nrows * calls_per_unit)
+    bool active;       // lane < nrows
+    bool write_gate;   // HSW_SKIP_GATE not set
+    // FlexGate column packing: cells at block-local index >= brk1 / brk2 are shifted
+    // by gap1 / gap2 more cells (the unused tail rows of a column); 0xffffffff = none
+    u32 brk1, gap1, brk2, gap2;
+    // lookup-advice column staging (RC only)
+    u16 *lk16;         // LDS
+    u32 lk;            // this lane's next slot (phase-local)
+    u32 lk_first;      // block-relative index of the phase-part's first lookup cell
+    u32 lks;           // lookup cells staged by this phase-part
+};
+
+// Compile-time emission cursor: POS = cells already in the current tile, FL =
+// tiles flushed so far in this phase, NA..ND = the (at most four: ch has four per
+// round, compression.rs:320-335) tile positions holding a field negation, -1 = none.
+// CN: the previous tile had a negation among its last three positions, i.e. one may have been carried
+// into this tile by the realigning flush (only then does the flush look at the runtime carry mask).
+template <int POS, int FL, int NA = -1, int NB = -1, int NC = -1, int ND = -1, bool CN = false>
+struct Cur {
+    static constexpr int pos = POS, fl = FL;
+    static constexpr int na = NA, nb = NB, nc = NC, nd = ND;
+    static constexpr bool cn = CN;
+};
+using CurStart = Cur<0, 0>;
+
+// Transpose `ncells` tile columns out to HBM: row r goes to cells
+// [cell_base + r*unit_cells + seg, +ncells).  Canonical form: lane pairs cover one
+// 32-byte cell (low / high 16 bytes), so a wave-wide store instruction writes
+// 1 KiB contiguous.  Montgomery / compact form: one lane per cell.
+// All addressing is a wave-uniform base pointer plus a 32-bit byte offset (one
+// block's stream spans far less than 4 GiB even with column-break gaps), so a store costs a
+// handful of VALU instructions instead of 64-bit pointer arithmetic per lane.
+template <class EM>
+DEV u32 packed_cell(const EM &em, u32 cl) {       // FlexGate column packing: add the gaps of the breaks passed
+    return cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u);
+}
+DEV void store16(char *base, u32 byte_off, uint4 v) { *reinterpret_cast<uint4 *>(base + (size_t)byte_off) = v; }
+DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base + (size_t)byte_off) = v; }
+
+// Realignment.  HBM writes run at full rate only when every contiguous run covers whole
+// 128-byte lines (measured: a stream starting 32 / 64 / 96 bytes past a line boundary runs
+// 47 / 26 / 47 % slower, tools/align_probe.py) -- but where a block's stream starts is dictated
+// by the circuit layout (digest frames, column breaks, odd max_rows).  So a unit that starts
+// `skew` cells past a line boundary keeps its tile in LDS columns [skew, skew + T): a flush
+// writes columns [0, T) -- a line-aligned window of the stream -- and carries the last `skew`
+// cells over into columns [0, skew) of the next tile.  Only the first and last few cells of a
+// unit are partial lines, and those meet the neighbouring unit's in L2 within the same flush.
+template <class EM, bool FULL>
+DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, bool cn) {
+    constexpr int T = EM::TILE;
+    constexpr int S = EM::STRIDE;
+    const u32 lane = threadIdx.x;
+    char *base = reinterpret_cast<char *>(em.out);
+    const bool packed = em.brk1 != 0xffffffffu;          // wave-uniform; false unless a pack plan is in force
+    const u32 skew = em.skew;
+    // A skewed unit shares its first line with the previous unit's tail, which is written at the END of
+    // the phase: the first 4 - skew cells of every unit but the wave's first are held back in em.head and
+    // appended to the previous row's tail in the last flush, so that the shared line is completed within
+    // one flush (a partial line costs a read-modify-write in HBM, and in a write-only stream the bus
+    // turnaround of that read is worth ~10 lines).
+    const bool hold_heads = FULL && fl == 0 && skew != 0u;
+    const u32 hc = (!FULL && fl != 0 && skew != 0u) ? 4u - skew : 0u;    // head cells appended per row now
+    const u32 hi = FULL ? (u32)T : ncells + skew;        // one past the last tile column written now
+    if (hold_heads && lane >= 1u && lane < em.nrows)
+        for (u32 j = skew; j < 4u; j++) em.head[lane * 3u + j - skew] = em.row0[j];
+    if (hc != 0u && lane >= 1u && lane < em.nrows)       // memory after row r's tail is row r+1's head
+        for (u32 j = 0; j < hc; j++) em.tile[(lane - 1u) * S + hi + j] = em.head[lane * 3u + j];
+    __syncthreads();
+    const u32 lo0 = fl == 0 ? skew : 0u;                 // first LDS column written now: row 0 ...
+    const u32 lo = hold_heads ? 4u : lo0;                // ... and the other rows
+    const u32 seg = (u32)fl * (u32)T - skew;             // column c holds unit cell seg + c (never used below lo)
+    const u32 cneg = cn ? em.carry_neg : 0u;             // cn is a compile-time constant at every call site
+    // is LDS column p a field negation?  tile position = p - skew; carried columns: bit mask
+    auto is_neg = [&](u32 p) -> bool {
+        if (skew == 0u)                                  // wave-uniform: the aligned case stays 4 compares
+            return na >= 0 && (p == (u32)na || p == (u32)nb || p == (u32)nc || p == (u32)nd);
+        if (p < skew) return fl != 0 && ((cneg >> p) & 1u);
+        const u32 q = p - skew;
+        return na >= 0 && (q == (u32)na || q == (u32)nb || q == (u32)nc || q == (u32)nd);
+    };
+    const bool any_neg = na >= 0 || cneg != 0u;
+    const bool first_skewed = FULL && fl == 0 && skew != 0u;      // wave-uniform: some leading columns are not written
+    if (em.write_gate && hi + hc > lo0) {
+        // partial flushes: every row writes columns [lo0, hi + hc), the last row only [lo0, hi)
+        const u32 ncols = hi + hc - lo0;
+        const u32 total_cells = em.nrows * ncols - hc;
+        // a partial flush writes ncells columns per row, or ncells + 4 when skewed (skew carried + 4 - skew
+        // appended): both are compile-time constants after inlining, so the row of piece i is two
+        // divisions by constants and a select instead of a runtime division
+        const bool wide_rows = hc != 0u;
+        auto row_of = [&](u32 i, u32 per_cell) -> u32 {
+            return wide_rows ? i / ((ncells + 4u) * per_cell) : i / ((ncells ? ncells : 1u) * per_cell);
+        };
+        if constexpr (EM::COMPACT) {
+            // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
+            // Negation cells keep x (their positions are static: hsw_neg_cells).  (skew is always 0 here)
+#pragma unroll 4
+            for (u32 i = lane; i < total_cells; i += 64) {
+                const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
+                const u32 p = lo0 + i - r * ncols;
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store8(base, cl * 8u, em.tile[r * S + p]);
+            }
+        } else if constexpr (EM::MONT) {
+            // full tiles index by the compile-time T (a shift) and skip the < 4 empty / held-back columns
+            // of a skewed unit's first tile; partial ones divide by the run length
+            const u32 total = FULL ? em.nrows * (u32)T : total_cells;
+            for (u32 i = lane; i < total; i += 64) {
+                const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
+                const u32 p = FULL ? i % (u32)T : lo0 + i - r * ncols;
+                if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
+                const u64 v = em.tile[r * S + p];
+                Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
+                if (any_neg) {                        // compile-time false for most tiles
+                    if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
+                }
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store16(base, cl * 32u, make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]));
+                store16(base, cl * 32u + 16u, make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]));
+            }
+        } else if (FULL && !packed) {
+            // the common case: a full tile, no column break in this block.  Lane l owns the
+            // 16-byte piece (l & 1) of LDS column (l >> 1) + 32 k of every row; LDS and HBM
+            // addresses advance by constants.
+            const u32 h = lane & 1u, p0 = lane >> 1;
+            const u64 *src = em.tile + p0;
+            u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
+            const u32 row_bytes = em.unit_cells * 32u;
+            for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+                const bool skip0 = first_skewed && p0 < (r == 0u ? lo0 : lo);
+#pragma unroll
+                for (int k = 0; k < T / 32; k++) {
+                    const u64 v = src[32 * k];
+                    const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+                    uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
+                    if (any_neg) {
+                        if (is_neg(p0 + 32u * (u32)k) && v != 0ull)   // cell holds p - x (neg gate, compression.rs:320-321)
+                            o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
+                                  : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
+                    }
+                    if (k != 0 || !skip0) store16(base, off + 1024u * (u32)k, o);
+                }
+            }
+        } else {
+            // (a FULL flush that lands here -- a column break in this block -- walks all T columns and
+            //  skips the empty / held-back ones of a skewed unit's first tile)
+            const u32 ppr = FULL ? 2u * (u32)T : 2u * ncols;        // 16-byte pieces per row
+            const u32 total = FULL ? em.nrows * ppr : 2u * total_cells;
+            for (u32 i = lane; i < total; i += 64) {
+                const u32 r = FULL ? i / (2u * (u32)T) : row_of(i, 2u);
+                const u32 q = i - r * ppr;
+                const u32 p = (FULL ? 0u : lo0) + (q >> 1), h = q & 1u;
+                if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
+                const u64 v = em.tile[r * S + p];
+                const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+                uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
+                if (any_neg) {
+                    if (is_neg(p) && v != 0ull)
+                        o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
+                              : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
+                }
+                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
+                store16(base, cl * 32u + h * 16u, o);
+            }
+        }
+    }
+    if (FULL && skew != 0u) {
+        // carry the last `skew` cells (LDS columns [T, T + skew)) over to columns [0, skew)
+        __syncthreads();                                 // every lane's stores have read the tile
+        u32 m = 0;
+        for (u32 j = 0; j < skew; j++) {
+            em.row0[j] = em.row0[T + j];
+            const u32 q = (u32)T + j - skew;             // tile position of the carried cell
+            if (na >= 0 && (q == (u32)na || q == (u32)nb || q == (u32)nc || q == (u32)nd)) m |= 1u << j;
+        }
+        em.carry_neg = (u32)__builtin_amdgcn_readfirstlane((int)m);     // wave-uniform: keep it scalar
+    }
+    __syncthreads();
+}
+
+template <class EM, class C>
+DEV auto emit(C, EM &em, u64 v) {
+    em.row[C::pos] = v;
+    if constexpr (C::pos + 1 == EM::TILE) {
+        flush_tile<EM, true>(em, EM::TILE, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+        constexpr int T3 = EM::TILE - 3;
+        constexpr bool carried = C::na >= T3 || C::nb >= T3 || C::nc >= T3 || C::nd >= T3;
+        return Cur<0, C::fl + 1, -1, -1, -1, -1, carried>{};
+    } else {
+        return Cur<C::pos + 1, C::fl, C::na, C::nb, C::nc, C::nd, C::cn>{};
+    }
+}
+// cell whose field value is -x (x small): stored as x, its position appended to the cursor's neg list
+template <class EM, class C>
+DEV auto emit_neg(C, EM &em, u64 x) {
+    static_assert(C::nd < 0, "more than four neg cells in one tile");
+    if constexpr (C::na < 0) return emit(Cur<C::pos, C::fl, C::pos, -1, -1, -1, C::cn>{}, em, x);
+    else if constexpr (C::nb < 0) return emit(Cur<C::pos, C::fl, C::na, C::pos, -1, -1, C::cn>{}, em, x);
+    else if constexpr (C::nc < 0) return emit(Cur<C::pos, C::fl, C::na, C::nb, C::pos, -1, C::cn>{}, em, x);
+    else return emit(Cur<C::pos, C::fl, C::na, C::nb, C::nc, C::pos, C::cn>{}, em, x);
+}
+
+// Units of a phase dealt to `parts` waves: part k expands the contiguous range
+// [k*per, min((k+1)*per, n_units)) with per = ceil(n_units / parts).
+DEV void part_units(u32 part, u32 parts, u32 n_units, u32 &unit_lo, u32 &nrows) {
+    const u32 per = (n_units + parts - 1) / parts;
+    unit_lo = part * per;
+    nrows = unit_lo >= n_units ? 0u : (n_units - unit_lo < per ? n_units - unit_lo : per);
+}
+// Unit expanded by this lane (idle lanes shadow the last active one).
+DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
+    const u32 lane = threadIdx.x;
+    u32 nrows, unit_lo;
+    part_units(part, parts, n_units, unit_lo, nrows);
+    return (nrows ? unit_lo : 0u) + (lane < nrows ? lane : (nrows ? nrows - 1 : 0));
+}
+
+// A phase is `n_units` independent units of `unit_cells` gate cells each.
+// Returns false if this wave has nothing to do in the phase (wave-uniform).
+template <class EM>
+DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
+                     u32 call_base, u32 calls_per_unit, u32 lk_base = 0, u32 lk_per_unit = 0) {
+    const u32 lane = threadIdx.x;
+    u32 nrows, unit_lo;
+    part_units(part, parts, n_units, unit_lo, nrows);
+    if (nrows == 0) unit_lo = 0;
+    em.nrows = nrows;
+    em.unit_cells = unit_cells;
+    em.cell_base = phase_off + unit_lo * unit_cells;
+    em.active = lane < nrows;
+    const u32 r = lane < nrows ? lane : (nrows ? nrows - 1 : 0);
+    em.unit = unit_lo + r;
+    em.call = r * calls_per_unit;
+    em.call_first = call_base + unit_lo * calls_per_unit;
+    em.calls = nrows * calls_per_unit;
+    em.lk = r * lk_per_unit;
+    em.lk_first = lk_base + unit_lo * lk_per_unit;
+    em.lks = nrows * lk_per_unit;
+    // realignment (flush_tile): only where every unit of the phase starts at the same offset within
+    // a 128-byte line (unit_cells % 4 == 0: words, schedule steps, rounds -- 98 % of the cells)
+    u32 skew = 0;
+    if constexpr (!EM::COMPACT) {
+        if ((unit_cells & 3u) == 0u) {
+            u32 cl = em.cell_base;
+            if (em.brk1 != 0xffffffffu) cl = packed_cell(em, cl);
+            skew = (cl + (u32)(reinterpret_cast<size_t>(em.out) >> 5)) & 3u;
+        }
+    }
+    em.skew = (u32)__builtin_amdgcn_readfirstlane((int)skew);           // wave-uniform: keep it scalar
+    em.carry_neg = 0;
+    em.row = em.row0 + skew;
+    return nrows != 0;
+}
+
+// Chip columns of the spread calls staged by this phase-part (spread.rs:196-233):
+// limb call n (absolute, counted from SpreadConfig.num_limb_sum = 0) lands in
+// column n % ncols at row n / ncols; buffer row 0 = row cursor0 / ncols.  Every
+// column receives one contiguous run of rows.
+template <int L, class EM>
+DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
+    constexpr int B = 16 / L;
+    constexpr u32 MASK = (1u << B) - 1u;
+    if (em.calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
+    __syncthreads();                                                   // d16 staged by all lanes
+    const u32 lane = threadIdx.x;
+    const u64 ncols = p.ncols;
+    const u64 first = block_first_limb + (u64)em.call_first * L;       // first limb call of this run
+    const u64 last = first + (u64)em.calls * L - 1;
+    const u64 row0 = p.cursor0 / ncols;
+    for (u64 c = 0; c < ncols; c++) {
+        if (last < c) continue;
+        const u64 row_lo = (first + ncols - 1 - c) / ncols;            // first row with row*ncols + c >= first
+        const u64 row_hi = (last - c) / ncols;                         // last row with row*ncols + c <= last
+        if (row_hi < row_lo) continue;
+        const u32 count = (u32)(row_hi - row_lo + 1);
+        const u32 n0 = (u32)(row_lo * ncols + c - first);              // run-relative limb index of row_lo
+        // wave-uniform column run base + 32-bit lane offsets
+        const size_t cell0 = (size_t)c * p.chip_col_stride + (size_t)(row_lo - row0);
+        constexpr u32 CB = EM::COMPACT ? 8u : 32u;
+        char *cdb = reinterpret_cast<char *>(p.chip_dense) + cell0 * CB;
+        char *csb = reinterpret_cast<char *>(p.chip_spread) + cell0 * CB;
+        if constexpr (EM::COMPACT) {
+            for (u32 k = lane; k < count; k += 64) {
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                store8(cdb, k * 8u, limb);
+                store8(csb, k * 8u, spread16(limb));
+            }
+        } else if constexpr (EM::MONT) {
+            for (u32 k = lane; k < count; k += 64) {
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                const Fe8 md = mont_from_u64<false>(limb, 0), ms = mont_from_u64<false>(spread16(limb), 0);
+                store16(cdb, k * 32u, make_uint4(md.l[0], md.l[1], md.l[2], md.l[3]));
+                store16(cdb, k * 32u + 16u, make_uint4(md.l[4], md.l[5], md.l[6], md.l[7]));
+                store16(csb, k * 32u, make_uint4(ms.l[0], ms.l[1], ms.l[2], ms.l[3]));
+                store16(csb, k * 32u + 16u, make_uint4(ms.l[4], ms.l[5], ms.l[6], ms.l[7]));
+            }
+        } else {
+            for (u32 i = lane; i < 2u * count; i += 64) {
+                const u32 k = i >> 1, hpart = i & 1u;
+                const u32 n = n0 + k * (u32)ncols;
+                const u32 call = n / L, j = n % L;
+                const u32 limb = ((u32)em.d16[call] >> (B * j)) & MASK;
+                store16(cdb, i * 16u, make_uint4(hpart ? 0u : limb, 0u, 0u, 0u));
+                store16(csb, i * 16u, make_uint4(hpart ? 0u : spread16(limb), 0u, 0u, 0u));
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Lookup-advice column (RC only): the values queued by enable_lookup, in queue
+// order, as one contiguous run per phase-part (RangeConfig::finalize, lib.rs:469).
+template <class EM>
+DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_base) {
+    if (em.lks == 0 || p.lookup == nullptr) return;
+    __syncthreads();
+    const u32 lane = threadIdx.x;
+    uint4 *out = reinterpret_cast<uint4 *>(p.lookup) + (lookup_block_base + em.lk_first) * 2u;
+    if constexpr (EM::COMPACT) {
+        u64 *out64 = reinterpret_cast<u64 *>(p.lookup) + lookup_block_base + em.lk_first;
+        for (u32 k = lane; k < em.lks; k += 64) out64[k] = em.lk16[k];
+    } else if constexpr (EM::MONT) {
+        for (u32 k = lane; k < em.lks; k += 64) {
+            const Fe8 m = mont_from_u64<false>(em.lk16[k], 0);
+            out[2 * k] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+            out[2 * k + 1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+        }
+    } else {
+        for (u32 i = lane; i < 2u * em.lks; i += 64) {
+            uint4 o;
+            o.x = (i & 1u) ? 0u : (u32)em.lk16[i >> 1];
+            o.y = 0; o.z = 0; o.w = 0;
+            out[i] = o;
+        }
+    }
+    __syncthreads();
+}
+
+template <int L, class EM, class C>
+DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
+    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+    else if (em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1, C::cn);      // the carried cells only
+    flush_chip<L>(em, p, block_first_limb);
+    if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
+}
+
+// enable_lookup: queue a (<= 16-bit) value for the lookup-advice column
+template <class EM>
+DEV void lookup16(EM &em, u32 v) {
+    if constexpr (EM::RC) {
+        if (em.active) em.lk16[em.lk] = (u16)v;
+        em.lk++;
+    }
+}
+// range_check(a, 32) at lookup_bits = 16: halo2-base lays out [limb0, limb1, 2^16, a]
+// (inner_product_left of the two limbs with [1, 2^16]) and looks both limbs up (A3).
+template <class EM, class C>
+DEV auto range_check32(C c, EM &em, u32 a) {
+    const u32 l0 = a & 0xffffu, l1 = a >> 16;
+    lookup16(em, l0);
+    lookup16(em, l1);
+    if constexpr (EM::RC) {
+        auto c1 = emit(c, em, l0);
+        auto c2 = emit(c1, em, l1);
+        auto c3 = emit(c2, em, 1u << 16);
+        return emit(c3, em, a);
+    } else {
+        return c;
+    }
+}
+
+// ---------------------------------------------------- halo2-base gate cells
+// (cell orders: DESIGN.md assumption A1).  Every function takes the cursor and
+// returns the advanced cursor; runtime results come back through references.
+template <class EM, class C>
+DEV auto g_lw(C c, EM &em, u64 v) { return emit(c, em, v); }                     // [v]
+template <class EM, class C>
+DEV auto g_add(C c, EM &em, u64 a, u64 b, u64 &out) {                            // [a, b, 1, a+b]
+    out = a + b;
+    auto c1 = emit(c, em, a);
+    auto c2 = emit(c1, em, b);
+    auto c3 = emit(c2, em, 1);
+    return emit(c3, em, out);
+}
+// mul_add(a, b, c) = a*b + c -> [c, a, b, out]; `out` is passed in (computed by
+// shifts by the caller: every b is a power of two or a 3-term sum of them).
+template <class EM, class C>
+DEV auto g_mul_add(C c, EM &em, u64 a, u64 b, u64 cc, u64 out) {
+    auto c1 = emit(c, em, cc);
+    auto c2 = emit(c1, em, a);
+    auto c3 = emit(c2, em, b);
+    return emit(c3, em, out);
+}
+
+// ------------------------------------------------------- spread.rs mirrors
+// SpreadConfig::spread (spread.rs:76-123) on a 16-bit dense value.
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_lw(C c, EM &em, u32 dense) {                               // :86-88
+    if constexpr (J == L) return c;
+    else {
+        constexpr int B = 16 / L;
+        auto c1 = g_lw(c, em, (dense >> (B * J)) & ((1u << B) - 1u));
+        return spread_limbs_lw<L, J + 1>(c1, em, dense);
+    }
+}
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_sum(C c, EM &em, u32 dense, u32 sum) {                     // :91-98
+    if constexpr (J == L) return c;
+    else {
+        constexpr int B = 16 / L;
+        const u32 limb = (dense >> (B * J)) & ((1u << B) - 1u);
+        const u32 ns = sum | (limb << (B * J));
+        auto c1 = g_mul_add(c, em, limb, 1u << (B * J), sum, ns);
+        return spread_limbs_sum<L, J + 1>(c1, em, dense, ns);
+    }
+}
+template <int L, int J, class EM, class C>
+DEV auto spread_limbs_acc(C c, EM &em, u32 dense, u32 acc, u32 &result) {        // :112-121
+    if constexpr (J == L) { result = acc; return c; }
+    else {
+        constexpr int B = 16 / L;
+        const u32 limb = (dense >> (B * J)) & ((1u << B) - 1u);
+        const u32 sl = spread16(limb);
+        auto c1 = g_lw(c, em, sl);                                               // spread_limb :225
+        const u32 na = acc | (sl << (2 * B * J));
+        auto c2 = g_mul_add(c1, em, sl, (u64)1 << (2 * B * J), acc, na);
+        return spread_limbs_acc<L, J + 1>(c2, em, dense, na, result);
+    }
+}
+template <int L, class EM, class C>
+DEV auto sc_spread(C c, EM &em, u32 dense, u32 &spread_out) {
+    if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced by flush_chip
+    em.call++;
+    auto c1 = spread_limbs_lw<L, 0>(c, em, dense);
+    auto c2 = spread_limbs_sum<L, 0>(c1, em, dense, 0u);
+    return spread_limbs_acc<L, 0>(c2, em, dense, 0u, spread_out);
+}
+
+// state_to_spread_u32 (compression.rs:215-246)
+template <int L, class EM, class C>
+DEV auto state_to_spread(C c, EM &em, u32 x) {
+    const u32 lo = x & 0xffffu, hi = x >> 16;
+    u32 unused;
+    auto c1 = g_lw(c, em, lo);                               // :230
+    auto c2 = g_lw(c1, em, hi);                              // :231
+    auto c3 = g_mul_add(c2, em, hi, 1u << 16, lo, x);        // :232-237
+    auto c4 = sc_spread<L>(c3, em, lo, unused);              // :243
+    return sc_spread<L>(c4, em, hi, unused);                 // :244
+}
+
+// mod_u32 (compression.rs:266-295); x < 2^35
+template <class EM, class C>
+DEV auto mod_u32(C c, EM &em, u64 x, u32 &lo_out) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    lo_out = lo;
+    auto c1 = g_lw(c, em, lo);                               // :280
+    auto c2 = g_lw(c1, em, hi);                              // :281
+    auto c3 = range_check32(c2, em, lo);                     // :282
+    return g_mul_add(c3, em, hi, (u64)1 << 32, lo, x);       // :283-288
+}
+
+// { spread(even); spread(odd); 2*odd_spread + even_spread } (compression.rs:344-354 etc.)
+template <int L, class EM, class C>
+DEV auto recheck_even_odd(C c, EM &em, u32 even, u32 odd) {
+    u32 es, os;
+    auto c1 = sc_spread<L>(c, em, even, es);
+    auto c2 = sc_spread<L>(c1, em, odd, os);
+    return g_mul_add(c2, em, 2, os, es, (u64)es + 2ull * (u64)os);
+}
+
+// sigma_generic (compression.rs:702-882).  S1..S3 are STARTS[1..3]; C0..C3 the
+// coeffs (sigma_lower drops the wrapped piece: two terms in C0, :658,:685).
+struct SigmaUpper0 {   // :600-608
+    static constexpr int S1 = 2, S2 = 13, S3 = 22;
+    static constexpr u64 C0 = (1ull << 60) + (1ull << 38) + (1ull << 20);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 42) + (1ull << 24);
+    static constexpr u64 C2 = (1ull << 22) + (1ull << 0) + (1ull << 46);
+    static constexpr u64 C3 = (1ull << 40) + (1ull << 18) + (1ull << 0);
+};
+struct SigmaUpper1 {   // :627-635
+    static constexpr int S1 = 6, S2 = 11, S3 = 25;
+    static constexpr u64 C0 = (1ull << 52) + (1ull << 42) + (1ull << 14);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 54) + (1ull << 26);
+    static constexpr u64 C2 = (1ull << 10) + (1ull << 0) + (1ull << 36);
+    static constexpr u64 C3 = (1ull << 38) + (1ull << 28) + (1ull << 0);
+};
+struct SigmaLower0 {   // :654-662
+    static constexpr int S1 = 3, S2 = 7, S3 = 18;
+    static constexpr u64 C0 = (1ull << 50) + (1ull << 28);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 56) + (1ull << 34);
+    static constexpr u64 C2 = (1ull << 8) + (1ull << 0) + (1ull << 42);
+    static constexpr u64 C3 = (1ull << 30) + (1ull << 22) + (1ull << 0);
+};
+struct SigmaLower1 {   // :681-689
+    static constexpr int S1 = 10, S2 = 17, S3 = 19;
+    static constexpr u64 C0 = (1ull << 30) + (1ull << 26);
+    static constexpr u64 C1 = (1ull << 0) + (1ull << 50) + (1ull << 46);
+    static constexpr u64 C2 = (1ull << 14) + (1ull << 0) + (1ull << 60);
+    static constexpr u64 C3 = (1ull << 18) + (1ull << 4) + (1ull << 0);
+};
+
+template <class SG, int L, class EM, class C>
+DEV auto sigma_generic(C c0, EM &em, u32 x, u32 &out) {
+    const u64 X = spread32(x);                               // x_spread.1 * 2^32 + x_spread.0
+    // :719-734 the four pieces, spread bits [2*start, 2*end) shifted to 0
+    const u64 pa = X & ((1ull << (2 * SG::S1)) - 1);
+    const u64 pb = (X >> (2 * SG::S1)) & ((1ull << (2 * (SG::S2 - SG::S1))) - 1);
+    const u64 pc = (X >> (2 * SG::S2)) & ((1ull << (2 * (SG::S3 - SG::S2))) - 1);
+    const u64 pd = X >> (2 * SG::S3);
+    auto c1 = g_lw(c0, em, pa);
+    auto c2 = g_lw(c1, em, pb);
+    auto c3 = g_lw(c2, em, pc);
+    auto c4 = g_lw(c3, em, pd);
+    // :736-754 recomposition
+    const u64 s1 = pa + (pb << (2 * SG::S1));
+    const u64 s2 = s1 + (pc << (2 * SG::S2));
+    const u64 s3 = s2 + (pd << (2 * SG::S3));
+    auto c5 = g_mul_add(c4, em, pb, 1ull << (2 * SG::S1), pa, s1);
+    auto c6 = g_mul_add(c5, em, pc, 1ull << (2 * SG::S2), s1, s2);
+    auto c7 = g_mul_add(c6, em, pd, 1ull << (2 * SG::S3), s2, s3);
+    // :755-760 x_composed
+    auto c8 = g_mul_add(c7, em, X >> 32, 1ull << 32, X & 0xffffffffull, X);
+    // :780-808 r_spread = sum coeff_i * piece_i  (< 2^64 by construction)
+    const u64 r1 = SG::C0 * pa;
+    const u64 r2 = r1 + SG::C1 * pb;
+    const u64 r3 = r2 + SG::C2 * pc;
+    const u64 r = r3 + SG::C3 * pd;
+    auto c9 = g_mul_add(c8, em, SG::C0, pa, 0, r1);
+    auto c10 = g_mul_add(c9, em, SG::C1, pb, r1, r2);
+    auto c11 = g_mul_add(c10, em, SG::C2, pc, r2, r3);
+    auto c12 = g_mul_add(c11, em, SG::C3, pd, r3, r);
+    // :811-836
+    const u32 r_lo = (u32)r, r_hi = (u32)(r >> 32);
+    auto c13 = g_lw(c12, em, r_lo);                          // :820
+    auto c14a = g_lw(c13, em, r_hi);                         // :821
+    auto c14b = range_check32(c14a, em, r_lo);               // :822
+    auto c14 = range_check32(c14b, em, r_hi);                // :823
+    auto c15 = g_mul_add(c14, em, r_hi, 1ull << 32, r_lo, r);
+    // :843-846
+    const u32 lo_even = even_bits(r_lo), lo_odd = even_bits(r_lo >> 1);
+    const u32 hi_even = even_bits(r_hi), hi_odd = even_bits(r_hi >> 1);
+    auto c16 = g_lw(c15, em, lo_even);
+    auto c17 = g_lw(c16, em, lo_odd);
+    auto c18 = g_lw(c17, em, hi_even);
+    auto c19 = g_lw(c18, em, hi_odd);
+    lookup16(em, lo_even); lookup16(em, lo_odd);             // range_check 16, spread.rs:160-161
+    lookup16(em, hi_even); lookup16(em, hi_odd);
+    auto c20 = recheck_even_odd<L>(c19, em, lo_even, lo_odd);     // :852-862
+    auto c21 = recheck_even_odd<L>(c20, em, hi_even, hi_odd);     // :863-873
+    out = (hi_even << 16) | lo_even;
+    return g_mul_add(c21, em, hi_even, 1u << 16, lo_even, out);   // :874-879
+}
+
+// ch (compression.rs:297-405); x, y, z are the dense words e, f, g
+template <int L, class EM, class C>
+DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
+    const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
+    const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
+    const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
+    const u32 MASK_EVEN_32 = 0x55555555u;
+    u64 p_lo, p_hi, q_lo, q_hi;
+    auto c1 = g_add(c0, em, x_lo, y_lo, p_lo);               // :309-313
+    auto c2 = g_add(c1, em, x_hi, y_hi, p_hi);               // :314-318
+    // neg: [a, -a, 1, 0]                                       :320-321
+    auto c3 = emit(c2, em, x_lo);
+    auto c4 = emit_neg(c3, em, x_lo);
+    auto c5 = emit(c4, em, 1);
+    auto c6 = emit(c5, em, 0);
+    auto c7 = emit(c6, em, x_hi);
+    auto c8 = emit_neg(c7, em, x_hi);
+    auto c9 = emit(c8, em, 1);
+    auto c10 = emit(c9, em, 0);
+    // three_add(Constant(MASK), -x, z)                         :322-335, :521-530
+    const u32 t_lo = MASK_EVEN_32 - x_lo, t_hi = MASK_EVEN_32 - x_hi;
+    auto c11 = emit(c10, em, MASK_EVEN_32);
+    auto c12 = emit_neg(c11, em, x_lo);
+    auto c13 = emit(c12, em, 1);
+    auto c14 = emit(c13, em, t_lo);
+    auto c15 = g_add(c14, em, t_lo, z_lo, q_lo);
+    auto c16 = emit(c15, em, MASK_EVEN_32);
+    auto c17 = emit_neg(c16, em, x_hi);
+    auto c18 = emit(c17, em, 1);
+    auto c19 = emit(c18, em, t_hi);
+    auto c20 = g_add(c19, em, t_hi, z_hi, q_hi);
+    // :336-343 four even/odd splits before any re-check
+    const u32 p_lo_even = even_bits((u32)p_lo), p_lo_odd = even_bits((u32)p_lo >> 1);
+    const u32 p_hi_even = even_bits((u32)p_hi), p_hi_odd = even_bits((u32)p_hi >> 1);
+    const u32 q_lo_even = even_bits((u32)q_lo), q_lo_odd = even_bits((u32)q_lo >> 1);
+    const u32 q_hi_even = even_bits((u32)q_hi), q_hi_odd = even_bits((u32)q_hi >> 1);
+    auto c21 = g_lw(c20, em, p_lo_even);
+    auto c22 = g_lw(c21, em, p_lo_odd);
+    auto c23 = g_lw(c22, em, p_hi_even);
+    auto c24 = g_lw(c23, em, p_hi_odd);
+    auto c25 = g_lw(c24, em, q_lo_even);
+    auto c26 = g_lw(c25, em, q_lo_odd);
+    auto c27 = g_lw(c26, em, q_hi_even);
+    auto c28 = g_lw(c27, em, q_hi_odd);
+    lookup16(em, p_lo_even); lookup16(em, p_lo_odd); lookup16(em, p_hi_even); lookup16(em, p_hi_odd);
+    lookup16(em, q_lo_even); lookup16(em, q_lo_odd); lookup16(em, q_hi_even); lookup16(em, q_hi_odd);
+    auto c29 = recheck_even_odd<L>(c28, em, p_lo_even, p_lo_odd);     // :344-354
+    auto c30 = recheck_even_odd<L>(c29, em, p_hi_even, p_hi_odd);     // :355-365
+    auto c31 = recheck_even_odd<L>(c30, em, q_lo_even, q_lo_odd);     // :366-376
+    auto c32 = recheck_even_odd<L>(c31, em, q_hi_even, q_hi_odd);     // :377-387
+    u64 out_lo, out_hi;
+    auto c33 = g_add(c32, em, p_lo_odd, q_lo_odd, out_lo);   // :388-392
+    auto c34 = g_add(c33, em, p_hi_odd, q_hi_odd, out_hi);   // :393-397
+    out = ((u32)out_hi << 16) + (u32)out_lo;
+    return g_mul_add(c34, em, out_hi, 1u << 16, out_lo, out);    // :398-403
+}
+
+// maj (compression.rs:460-519)
+template <int L, class EM, class C>
+DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
+    const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
+    const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
+    const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
+    u64 t, m_lo64, m_hi64;
+    auto c1 = g_add(c0, em, x_lo, y_lo, t);
+    auto c2 = g_add(c1, em, t, z_lo, m_lo64);                // :472-478
+    auto c3 = g_add(c2, em, x_hi, y_hi, t);
+    auto c4 = g_add(c3, em, t, z_hi, m_hi64);                // :479-485
+    const u32 m_lo = (u32)m_lo64, m_hi = (u32)m_hi64;
+    const u32 m_lo_even = even_bits(m_lo), m_lo_odd = even_bits(m_lo >> 1);
+    const u32 m_hi_even = even_bits(m_hi), m_hi_odd = even_bits(m_hi >> 1);
+    auto c5 = g_lw(c4, em, m_lo_even);                       // :486-487
+    auto c6 = g_lw(c5, em, m_lo_odd);
+    auto c7 = g_lw(c6, em, m_hi_even);                       // :488-489
+    auto c8 = g_lw(c7, em, m_hi_odd);
+    lookup16(em, m_lo_even); lookup16(em, m_lo_odd); lookup16(em, m_hi_even); lookup16(em, m_hi_odd);
+    auto c9 = recheck_even_odd<L>(c8, em, m_lo_even, m_lo_odd);      // :490-500
+    auto c10 = recheck_even_odd<L>(c9, em, m_hi_even, m_hi_odd);     // :501-511
+    out = (m_hi_odd << 16) | m_lo_odd;
+    return g_mul_add(c10, em, m_hi_odd, 1u << 16, m_lo_odd, out);    // :512-517
+}
+
+// --------------------------------------------------------------- the kernel
+// T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
+// units one wave expands per phase; a block needs parts >= 64/R waves.
+template <int L, int T, int R, int REPR, bool RC>
+__global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
+    using LY = Lay<L, RC>;
+    static_assert(R * (T + 3) * 8 >= 800, "tile must be able to hold the chain seeds");
+    // The chain seeds live in LDS only until every lane has pulled its own into
+    // registers; the tile then reuses the same bytes (keeps the workgroup at
+    // <= 20 KiB of LDS = 8 waves per CU, so 4,096 blocks are exactly 2 waves of
+    // residency on 256 CUs).
+    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * (T + 3)];   // +1 scratch row for lanes >= R; +3 carry columns
+    u32 *sW = reinterpret_cast<u32 *>(s_tile);   // [64]
+    u32 *sA = sW + 64;         // [68] sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
+    u32 *sE = sA + 68;         // [68] sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
+    __shared__ u64 s_head[R * 3];                 // realignment: held-back first cells of every unit (flush_tile)
+    __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
+    __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
+
+    const u32 lane = threadIdx.x;
+    const u32 parts = p.parts;                   // waves per block (power of two <= 16)
+    const size_t blk = blockIdx.x / parts;
+    const u32 part = blockIdx.x % parts;
+
+    // ---- chain phase: plain SHA-256 of this block, wave-uniform -------------
+    {
+        const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
+        const u32 *ps = p.pre_states + 8 * blk;
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            w[i] = __builtin_bswap32(bw[i]);                 // big-endian words (compression.rs:31-47)
+            if (lane == 0) sW[i] = w[i];
+        }
+        u32 a = ps[0], b = ps[1], c = ps[2], d = ps[3], e = ps[4], f = ps[5], g = ps[6], h = ps[7];
+        if (lane == 0) {
+            sA[0] = d; sA[1] = c; sA[2] = b; sA[3] = a;
+            sE[0] = h; sE[1] = g; sE[2] = f; sE[3] = e;
+        }
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                const u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                const u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+                if (lane == 0) sW[t] = w[t & 15];
+            }
+            const u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+            const u32 chv = (e & f) ^ (~e & g);
+            const u32 t1 = h + S1 + chv + K256[t] + w[t & 15];
+            const u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+            const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+            const u32 t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+            if (lane == 0) { sA[t + 4] = a; sE[t + 4] = e; }
+        }
+        if (p.next_states != nullptr && lane == 0 && part == 0) {
+            u32 *ns = p.next_states + 8 * blk;               // compression.rs:197-212
+            ns[0] = ps[0] + a; ns[1] = ps[1] + b; ns[2] = ps[2] + c; ns[3] = ps[3] + d;
+            ns[4] = ps[4] + e; ns[5] = ps[5] + f; ns[6] = ps[6] + g; ns[7] = ps[7] + h;
+        }
+    }
+    __syncthreads();
+
+    // ---- every lane pulls the seeds of its units into registers -------------
+    auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };   // a..d = sA[3..0], e..h = sE[3..0]
+    const u32 u16_ = lane_unit(part, parts, 16), us = lane_unit(part, parts, 48);
+    const u32 ust = lane_unit(part, parts, 6), ur = lane_unit(part, parts, 64), uf = lane_unit(part, parts, 8);
+    const u32 seed_word = sW[u16_];
+    const u32 seed_w2 = sW[us + 14], seed_w15 = sW[us + 1], seed_w7 = sW[us + 9], seed_w16 = sW[us];
+    const u32 seed_state = pre_word(ust < 3 ? ust : ust + 1);
+    const u32 seed_a = sA[ur + 3], seed_b = sA[ur + 2], seed_c = sA[ur + 1], seed_d = sA[ur];
+    const u32 seed_e = sE[ur + 3], seed_f = sE[ur + 2], seed_g = sE[ur + 1], seed_h = sE[ur];
+    const u32 seed_wr = sW[ur], seed_k = K256[ur];
+    const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
+    __syncthreads();           // seeds are in registers: the tile may now overwrite them
+
+    using EM = Em<T, R, REPR, RC>;
+    EM em;
+    em.lk16 = s_lk16;
+    em.tile = s_tile;
+    em.row0 = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 3);   // lanes >= R never flush: scratch row
+    em.row = em.row0;
+    em.skew = 0;
+    em.carry_neg = 0;
+    em.head = s_head;
+    em.d16 = s_d16;
+    {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
+        u64 first = (u64)blk * (u64)LY::GATE_CELLS;
+        if constexpr (RC)          // whole-digest streams: every frame_every blocks a digest frame sits in between
+            if (p.frame_every) first += (u64)(blk / p.frame_every) * p.frame_cells;
+        u64 gap0 = 0;
+        em.brk1 = em.brk2 = 0xffffffffu;
+        em.gap1 = em.gap2 = 0;
+        for (u32 k = 0; k < p.n_breaks; k++) {
+            const u64 bc = p.break_cell[k];
+            if (bc <= first) gap0 += p.break_gap[k];
+            else if (bc < first + (u64)LY::GATE_CELLS) {
+                if (em.brk1 == 0xffffffffu) { em.brk1 = (u32)(bc - first); em.gap1 = (u32)p.break_gap[k]; }
+                else { em.brk2 = (u32)(bc - first); em.gap2 = (u32)p.break_gap[k]; }
+            }
+        }
+        if constexpr (REPR == 2)   // compact: 8-byte cells
+            em.out = reinterpret_cast<uint4 *>(reinterpret_cast<u64 *>(p.gate) + (size_t)(first + gap0));
+        else
+            em.out = reinterpret_cast<uint4 *>(p.gate) + (size_t)(first + gap0) * 2u;
+    }
+    size_t lk_blk = (size_t)blk * (size_t)LY::LOOKUP_CELLS;
+    if constexpr (RC)
+        if (p.frame_every) lk_blk += (size_t)(blk / p.frame_every) * (size_t)p.frame_lookups;
+    em.write_gate = (p.flags & HSW_K_SKIP_GATE) == 0u;
+    const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
+
+    // ---- words: compression.rs:31-47, 16 units of 4 mul_add ----------------
+    if (phase_begin(em, part, parts, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
+        const u32 word = seed_word;                          // bytes[3 - idx] * 2^(8 idx) + sum
+        const u32 b0 = word & 0xffu, b1 = (word >> 8) & 0xffu, b2 = (word >> 16) & 0xffu, b3 = word >> 24;
+        const u32 s0 = b0, s1 = s0 | (b1 << 8), s2 = s1 | (b2 << 16);
+        auto c1 = g_mul_add(CurStart{}, em, b0, 1u, 0u, s0);
+        auto c2 = g_mul_add(c1, em, b1, 1u << 8, s0, s1);
+        auto c3 = g_mul_add(c2, em, b2, 1u << 16, s1, s2);
+        auto c4 = g_mul_add(c3, em, b3, 1u << 24, s2, word);
+        phase_end<L>(c4, em, p, blk_limb0, lk_blk);
+    }
+
+    // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
+    if (phase_begin(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
+        auto c1 = state_to_spread<L>(CurStart{}, em, seed_word);
+        phase_end<L>(c1, em, p, blk_limb0, lk_blk);
+    }
+
+    // ---- schedule: compression.rs:57-96, 48 units --------------------------
+    if (phase_begin(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED,
+                    LY::LK_OFF_SCHED, LY::LK_SCHED)) {
+        const u32 w2 = seed_w2, w15 = seed_w15, w7 = seed_w7, w16 = seed_w16;   // W[idx-2], [idx-15], [idx-7], [idx-16]
+        u32 term1, term3, new_w;
+        u64 sum;
+        auto c1 = sigma_generic<SigmaLower1, L>(CurStart{}, em, w2, term1);    // :60
+        auto c2 = sigma_generic<SigmaLower0, L>(c1, em, w15, term3);           // :61
+        auto c3 = g_add(c2, em, term1, w7, sum);                               // :65-69
+        auto c4 = g_add(c3, em, sum, term3, sum);                              // :70-74
+        auto c5 = g_add(c4, em, sum, w16, sum);                                // :75-79
+        auto c6 = mod_u32(c5, em, sum, new_w);                                 // :80
+        auto c7 = state_to_spread<L>(c6, em, new_w);                           // :90
+        phase_end<L>(c7, em, p, blk_limb0, lk_blk);
+    }
+
+    // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
+    if (phase_begin(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
+        auto c1 = state_to_spread<L>(CurStart{}, em, seed_state);
+        phase_end<L>(c1, em, p, blk_limb0, lk_blk);
+    }
+
+    // ---- 64 rounds: compression.rs:125-196 ---------------------------------
+    if (phase_begin(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND,
+                    LY::LK_OFF_ROUNDS, LY::LK_ROUND)) {
+        const u32 a = seed_a, b = seed_b, c = seed_c, d = seed_d;
+        const u32 e = seed_e, f = seed_f, g = seed_g, h = seed_h;
+        u32 sig1, chv, t1, sig0, mjv, t2, e_new, a_new;
+        u64 s;
+        auto c1 = sigma_generic<SigmaUpper1, L>(CurStart{}, em, e, sig1);      // :130
+        auto c2 = ch_gadget<L>(c1, em, e, f, g, chv);                          // :131
+        auto c3 = g_add(c2, em, h, sig1, s);                                   // :138-142
+        auto c4 = g_add(c3, em, s, chv, s);                                    // :143-147
+        auto c5 = g_add(c4, em, s, seed_k, s);                                 // :148-152
+        auto c6 = g_add(c5, em, s, seed_wr, s);                                // :153-157
+        auto c7 = mod_u32(c6, em, s, t1);                                      // :158
+        auto c8 = sigma_generic<SigmaUpper0, L>(c7, em, a, sig0);              // :164
+        auto c9 = maj_gadget<L>(c8, em, a, b, c, mjv);                         // :165
+        auto c10 = g_add(c9, em, sig0, mjv, s);                                // :166-170
+        auto c11 = mod_u32(c10, em, s, t2);                                    // :171
+        auto c12 = g_add(c11, em, d, t1, s);                                   // :181
+        auto c13 = mod_u32(c12, em, s, e_new);                                 // :182
+        auto c14 = state_to_spread<L>(c13, em, e_new);                         // :184
+        auto c15 = g_add(c14, em, t1, t2, s);                                  // :192
+        auto c16 = mod_u32(c15, em, s, a_new);                                 // :193
+        auto c17 = state_to_spread<L>(c16, em, a_new);                         // :195
+        phase_end<L>(c17, em, p, blk_limb0, lk_blk);
+    }
+
+    // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
+    if (phase_begin(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
+        u64 s;
+        u32 lo;
+        auto c1 = g_add(CurStart{}, em, seed_fx, seed_fy, s);
+        auto c2 = mod_u32(c1, em, s, lo);
+        phase_end<L>(c2, em, p, blk_limb0, lk_blk);
+    }
+}
+
+// ------------------------------------------------------------------ launch
+template <int L, int T, int R, bool RC>
+static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
+    if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
+    const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
+    if (p.flags & HSW_K_MONTGOMERY)
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 1, RC>), grid, block, 0, stream, p);
+    else if (p.flags & HSW_K_COMPACT)
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 2, RC>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 0, RC>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int L>
+hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
+    if (p.n_blocks == 0) return hipSuccess;
+    if (p.flags & HSW_K_INTERNALS) {
+        // halo2-base internals (A3) are built for the reference's 8-bit table only
+        if constexpr (L == 2) {
+            switch (tile) {
+                case 64: return launch_expand_LTR<L, 64, 32, true>(p, stream);
+                case 128: return launch_expand_LTR<L, 128, 16, true>(p, stream);
+                default: return launch_expand_LTR<L, 32, 64, true>(p, stream);
+            }
+        } else return hipErrorInvalidValue;
+    }
+    switch (tile) {
+        case 6416: if constexpr (L == 2) return launch_expand_LTR<L, 64, 16, false>(p, stream); else return hipErrorInvalidValue;
+        case 32: return launch_expand_LTR<L, 32, 64, false>(p, stream);
+        case 64: if constexpr (L == 2) return launch_expand_LTR<L, 64, 32, false>(p, stream); else return hipErrorInvalidValue;
+        case 128: if constexpr (L == 2) return launch_expand_LTR<L, 128, 16, false>(p, stream); else return hipErrorInvalidValue;
+        // [8][256], [4][512] and [2][768] tiles (8-24 KiB runs) were measured too: they need 8-32 waves
+        // per block, and the redundant chain work then costs more than the longer runs gain
+        // (1.80 / 1.99 / 2.55 ms against 1.72-1.78 ms).
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace hsw
+#endif

@@ -1,0 +1,633 @@
+// hsw_gadget.cpp -- Sha256DynamicConfig / Context mirror (see hsw_gadget.hpp)
+// and its C ABI (include/hsw.h, "gadget front-end").
+#include "hsw_gadget.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "hsw_kernels.h"
+
+namespace hsw {
+
+namespace {
+
+const uint32_t K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+const uint32_t INIT_STATE[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,      // compression.rs:1003-1012
+                                0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+// What sha2::compress256 does for the precomputed prefix (lib.rs:160).  The
+// prefix is by definition NOT part of the circuit, so the reference hashes it
+// on the CPU too; this is not a fallback of the witness path.
+void plain_compress(uint32_t st[8], const uint8_t *block) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)block[4 * i] << 24) | ((uint32_t)block[4 * i + 1] << 16) |
+               ((uint32_t)block[4 * i + 2] << 8) | block[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+int digest_prepare(const uint8_t *input, size_t input_byte_size, size_t precomputed_input_len,
+                   size_t max_variable_byte_size, DigestPlan *plan) {
+    if (!plan || (!input && input_byte_size)) return HSW_ERR_INVALID_ARG;
+    const size_t one_round_size = 64;                                         // lib.rs:48
+    if (max_variable_byte_size % one_round_size != 0) return HSW_ERR_SHAPE;   // lib.rs:57-59
+    const size_t input_byte_size_with_9 = input_byte_size + 9;                // lib.rs:78
+    const size_t num_round = (input_byte_size_with_9 + one_round_size - 1) / one_round_size;   // lib.rs:80-84
+    const size_t padded_size = one_round_size * num_round;                    // lib.rs:85
+    if (precomputed_input_len % one_round_size != 0) return HSW_ERR_SHAPE;    // lib.rs:89
+    if (precomputed_input_len > padded_size ||
+        padded_size - precomputed_input_len > max_variable_byte_size)
+        return HSW_ERR_TOO_LARGE;                                             // lib.rs:90
+    const size_t zero_padding_byte_size = padded_size - input_byte_size_with_9;               // lib.rs:91
+    const size_t remaining_byte_size = max_variable_byte_size + precomputed_input_len - padded_size;   // lib.rs:92
+    const size_t precomputed_round = precomputed_input_len / one_round_size;  // lib.rs:93
+    const size_t total = max_variable_byte_size + precomputed_input_len;
+
+    std::vector<uint8_t> padded(total, 0);                                    // lib.rs:98-117
+    if (input_byte_size) std::memcpy(padded.data(), input, input_byte_size);
+    size_t n = input_byte_size;
+    padded[n++] = 0x80;                                                       // lib.rs:99
+    n += zero_padding_byte_size;                                              // lib.rs:100-102
+    const uint64_t bitlen = 8ull * (uint64_t)input_byte_size;                 // lib.rs:103-108 (big-endian)
+    for (int i = 7; i >= 0; i--) padded[n++] = (uint8_t)(bitlen >> (8 * i));
+    if (n != num_round * one_round_size) return HSW_ERR_INVALID_ARG;          // lib.rs:110
+    if (n + remaining_byte_size != total) return HSW_ERR_INVALID_ARG;         // lib.rs:111-117
+
+    std::memcpy(plan->init_state, INIT_STATE, sizeof INIT_STATE);             // lib.rs:155
+    for (size_t r = 0; r < precomputed_round; r++)                            // lib.rs:156-160
+        plain_compress(plan->init_state, padded.data() + r * one_round_size);
+    plan->blocks.assign(padded.begin() + (ptrdiff_t)precomputed_input_len, padded.end());   // lib.rs:170
+    plan->num_round = num_round;
+    plan->precomputed_round = precomputed_round;
+    plan->target_round = num_round - precomputed_round;
+    plan->max_variable_round = max_variable_byte_size / one_round_size;
+    return HSW_OK;
+}
+
+int Sha256DynamicConfig::configure(const std::vector<size_t> &sizes, uint32_t num_bits_lookup,
+                                   uint32_t num_advice_columns, bool is_input_range_check,
+                                   Sha256DynamicConfig *out) {
+    if (!out) return HSW_ERR_INVALID_ARG;
+    for (size_t b : sizes)
+        if (b % 64 != 0) return HSW_ERR_SHAPE;                                // lib.rs:57-59
+    hsw_shape s;
+    const int rc = hsw_shape_query(num_bits_lookup, num_advice_columns, &s);  // SpreadConfig::configure, spread.rs:37
+    if (rc != HSW_OK) return rc;
+    out->max_variable_byte_sizes = sizes;
+    out->cur_hash_idx = 0;                                                    // lib.rs:66
+    out->num_bits_lookup = num_bits_lookup;
+    out->num_advice_columns = num_advice_columns;
+    out->is_input_range_check = is_input_range_check;
+    return HSW_OK;
+}
+
+std::vector<std::pair<uint64_t, uint64_t>> Sha256DynamicConfig::load() const {
+    std::vector<std::pair<uint64_t, uint64_t>> rows;                          // spread.rs:169-189
+    for (uint64_t idx = 0; idx < (1ull << num_bits_lookup); idx++) {
+        uint64_t sp = 0;
+        for (int b = 0; b < 32; b++) sp |= ((idx >> b) & 1ull) << (2 * b);
+        rows.emplace_back(idx, sp);
+    }
+    return rows;
+}
+
+Context::~Context() {
+    (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
+    (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
+    (void)hipFree(d_init_states); (void)hipFree(d_lookup);
+}
+
+int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
+    if (!engine || !out) return HSW_ERR_INVALID_ARG;
+    *out = nullptr;
+    hsw_shape s;
+    int rc = hsw_engine_shape(engine, &s);
+    if (rc != HSW_OK) return rc;
+    if (s.num_bits_lookup != num_bits_lookup || s.num_advice_columns != num_advice_columns)
+        return HSW_ERR_SHAPE;
+    Context *c = new (std::nothrow) Context();
+    if (!c) return HSW_ERR_NOMEM;
+    c->engine = engine;
+    c->shape = s;
+    size_t total = 0;
+    for (size_t b : max_variable_byte_sizes) total += b / 64;
+    c->capacity_blocks = total;
+    c->chip_col_stride = (size_t)hsw_chip_rows(&s, 0, total);
+    c->init_capacity = max_variable_byte_sizes.size();
+    const size_t nb = total ? total : 1, nh = c->init_capacity ? c->init_capacity : 1;
+    size_t gate_cells = nb * (size_t)s.gate_cells_per_block;
+    if (whole_digest) {
+        if (s.mode != HSW_MODE_HALO2_INTERNALS) { delete c; return HSW_ERR_INVALID_ARG; }
+        c->whole = true;
+        uint64_t cells = 1, lookups = 0;                      // 1: the Context's zero cell
+        for (size_t b : max_variable_byte_sizes) {
+            hsw_frame_shape fs;
+            rc = hsw_frame_query(&s, b, is_input_range_check ? 1 : 0, &fs);
+            if (rc == HSW_OK && fs.n_blocks == 0) rc = HSW_ERR_UNSUPPORTED;
+            if (rc != HSW_OK) { delete c; return rc; }
+            cells += fs.digest_cells;
+            lookups += fs.digest_lookups;
+        }
+        c->gate_capacity = cells;
+        c->lookup_capacity = lookups;
+        gate_cells = (size_t)cells;
+    }
+    hipError_t he = hipMalloc(&c->d_gate, gate_cells * HSW_CELL_BYTES);
+    if (he == hipSuccess && whole_digest)
+        he = hipMalloc(&c->d_lookup, (size_t)(c->lookup_capacity ? c->lookup_capacity : 1) * HSW_CELL_BYTES);
+    const size_t col_bytes = (size_t)s.num_advice_columns * (c->chip_col_stride ? c->chip_col_stride : 1) * HSW_CELL_BYTES;
+    if (he == hipSuccess) he = hipMalloc(&c->d_chip_dense, col_bytes);
+    if (he == hipSuccess) he = hipMalloc(&c->d_chip_spread, col_bytes);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_next_states, nb * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_blocks, nb * 64);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_pre_states, nb * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_init_states, nh * 32);
+    if (he == hipSuccess) he = hipMemset(c->d_chip_dense, 0, col_bytes);
+    if (he == hipSuccess) he = hipMemset(c->d_chip_spread, 0, col_bytes);
+    if (he != hipSuccess) {
+        delete c;
+        return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+    }
+    *out = c;
+    return HSW_OK;
+}
+
+int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint64_t rows) {
+    if (!whole || blocks_done != 0 || gate_cursor != 0) return HSW_ERR_INVALID_ARG;
+    const uint64_t G = shape.gate_cells_per_block;
+    if (rows < G + 16) return HSW_ERR_INVALID_ARG;        // keeps a block inside <= 2 columns (kernel: <= 2 breaks per block)
+    size_t n = 0;
+    if (hsw_gate_tape(&shape, nullptr, 0, &n) != HSW_OK) return HSW_ERR_INVALID_ARG;
+    std::vector<uint8_t> block_tape(n);
+    hsw_gate_tape(&shape, block_tape.data(), n, nullptr);
+    std::vector<uint64_t> bc, bg;
+    uint64_t row = 0, cell = 0;
+    auto walk = [&](const std::vector<uint8_t> &lens) {
+        for (uint8_t len : lens) {
+            if (row + len >= rows) {                      // halo2-lib v0.2.x assign_region: next column (A3-iii)
+                bc.push_back(cell); bg.push_back(rows - row);
+                row = 0;
+            }
+            row += len; cell += len;
+        }
+    };
+    bool zero = false;
+    for (size_t b : sizes) {
+        for (int section = 0; section < 2; section++) {
+            if (section == 1) {
+                if (!zero) { walk({1}); zero = true; }    // Context.zero_cell, first load_zero
+                for (size_t k = 0; k < b / 64; k++) {
+                    if (row + G + 8 < rows) { row += G; cell += G; }
+                    else walk(block_tape);
+                }
+            }
+            size_t m = 0;
+            int rc = hsw_frame_tape(&shape, b, rc_inputs ? 1 : 0, section, nullptr, 0, &m);
+            if (rc != HSW_OK) return rc;
+            std::vector<uint8_t> t(m);
+            hsw_frame_tape(&shape, b, rc_inputs ? 1 : 0, section, t.data(), m, nullptr);
+            walk(t);
+        }
+    }
+    if (bc.size() > HSW_MAX_BREAKS) return HSW_ERR_TOO_LARGE;
+    const uint64_t cols = bc.size() + 1;
+    int device = 0;
+    hsw_engine_stream(engine, nullptr, &device);
+    DeviceScope ds2(device);
+    if (!ds2.ok) return HSW_ERR_NO_DEVICE;
+    void *img = nullptr;
+    hipError_t he = hipMalloc(&img, (size_t)(cols * rows) * HSW_CELL_BYTES);
+    if (he == hipSuccess) he = hipMemset(img, 0, (size_t)(cols * rows) * HSW_CELL_BYTES);   // unassigned advice cells are 0
+    if (he != hipSuccess) { if (img) (void)hipFree(img); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
+    (void)hipFree(d_gate);
+    d_gate = img;
+    max_rows = rows;
+    columns = cols;
+    break_cell.swap(bc);
+    break_gap.swap(bg);
+    return HSW_OK;
+}
+
+void Context::position(uint64_t cell, uint64_t *column, uint64_t *row) const {
+    uint64_t at = cell;
+    for (size_t k = 0; k < break_cell.size(); k++)
+        if (break_cell[k] <= cell) at += break_gap[k];
+    if (max_rows) { if (column) *column = at / max_rows; if (row) *row = at % max_rows; }
+    else { if (column) *column = 0; if (row) *row = at; }
+}
+
+int Sha256DynamicConfig::digest(Context &ctx, const uint8_t *input, size_t input_len,
+                                size_t precomputed_input_len, AssignedHashResult *result) {
+    return digest_batch(ctx, 1, &input, &input_len, &precomputed_input_len, result);
+}
+
+int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *const *inputs,
+                                      const size_t *input_lens, const size_t *precomputed_input_lens,
+                                      AssignedHashResult *results) {
+    if (!results || !inputs || !input_lens) return HSW_ERR_INVALID_ARG;
+    if (n == 0) return HSW_OK;
+    // max_variable_byte_sizes[cur_hash_idx] must exist for every hash (lib.rs:86 would panic)
+    if (cur_hash_idx + n > max_variable_byte_sizes.size()) return HSW_ERR_INVALID_ARG;
+
+    // ---- host: lib.rs:77-160 for every message; nothing is committed on error ----
+    std::vector<DigestPlan> plans(n);
+    size_t batch_blocks = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t max_sz = max_variable_byte_sizes[cur_hash_idx + i];
+        const int rc = digest_prepare(inputs[i], input_lens[i],
+                                      precomputed_input_lens ? precomputed_input_lens[i] : 0, max_sz, &plans[i]);
+        if (rc != HSW_OK) return rc;
+        batch_blocks += plans[i].max_variable_round;
+    }
+    if (ctx.blocks_done + batch_blocks > ctx.capacity_blocks || n > ctx.init_capacity) return HSW_ERR_INVALID_ARG;
+
+    std::vector<uint8_t> h_blocks(batch_blocks * 64 ? batch_blocks * 64 : 1);
+    std::vector<uint32_t> h_init(n * 8), h_offsets(n + 1);
+    size_t off = 0;
+    for (size_t i = 0; i < n; i++) {
+        h_offsets[i] = (uint32_t)off;
+        if (!plans[i].blocks.empty()) std::memcpy(h_blocks.data() + off * 64, plans[i].blocks.data(), plans[i].blocks.size());
+        std::memcpy(&h_init[8 * i], plans[i].init_state, 32);
+        off += plans[i].max_variable_round;
+    }
+    h_offsets[n] = (uint32_t)off;
+    // The plain SHA chain (pre-state of every block, lib.rs:188,236) is the only serial
+    // part: ~4 us per block on one GPU lane, ~0.4 us on the host.  A small batch (one
+    // digest of the bench circuit is 16 blocks) is chained here, next to the prefix
+    // pre-hash the reference also does on the CPU (lib.rs:153-160), which saves a
+    // dependent kernel launch; a big batch uses hsw_chain_var_kernel, one lane per message.
+    // Either way the witness cells -- and the next_states the digest is read from -- come
+    // from the GPU.
+    const bool host_chain = batch_blocks <= 2048;
+    std::vector<uint32_t> h_pre;
+    if (host_chain) {
+        h_pre.resize(batch_blocks * 8 ? batch_blocks * 8 : 1);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t st[8];
+            std::memcpy(st, plans[i].init_state, 32);
+            for (size_t j = 0; j < plans[i].max_variable_round; j++) {
+                const size_t b = h_offsets[i] + j;
+                std::memcpy(&h_pre[8 * b], st, 32);
+                plain_compress(st, h_blocks.data() + 64 * b);
+            }
+        }
+    }
+
+    // ---- device: chain pre-pass + ONE expansion launch for the whole batch ----
+    hipStream_t stream = nullptr;
+    int device = 0;
+    hsw_engine_stream(ctx.engine, reinterpret_cast<void **>(&stream), &device);
+    DeviceScope ds(device);
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
+    const size_t b0 = ctx.blocks_done;
+    uint8_t *d_blk = ctx.d_blocks + 64 * b0;
+    uint32_t *d_pre = ctx.d_pre_states + 8 * b0;
+    uint32_t *d_next = ctx.d_next_states + 8 * b0;
+    uint32_t *d_off = nullptr;
+    std::vector<uint32_t> h_next(batch_blocks * 8 ? batch_blocks * 8 : 1);
+    hipError_t he = hipSuccess;
+    int rc = HSW_OK;
+    std::vector<hsw_frame_desc> frames;
+    uint64_t new_gate_cursor = ctx.gate_cursor, new_lookup_cursor = ctx.lookup_cursor;
+    do {
+        if (batch_blocks == 0) break;
+        if ((he = hipMemcpyAsync(d_blk, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        if (host_chain) {
+            if ((he = hipMemcpyAsync(d_pre, h_pre.data(), batch_blocks * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        } else {
+            if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
+            if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+            if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+            if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
+        }
+        const size_t G = ctx.shape.gate_cells_per_block;
+        const size_t cb = hsw_cell_bytes(ctx.repr_flags);
+        const uint32_t ncols = ctx.shape.num_advice_columns;
+        if (!ctx.whole) {
+            // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
+            // Column buffers are addressed from absolute row 0 (cursor origin of the context).
+            const uint64_t row_shift = ctx.num_limb_sum / ncols;
+            rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
+                                    static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb,
+                                    static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb,
+                                    static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb,
+                                    ctx.chip_col_stride, d_next, ctx.repr_flags);
+        } else {
+            // whole-digest stream: prologue | [zero cell] | blocks | epilogue per digest (hsw_frame.hpp).
+            // Consecutive digests of equal size are ONE expansion launch (the kernel skips the frame
+            // between their block streams); all frames of the batch are one hsw_frame_kernel launch.
+            const size_t LK = ctx.shape.lookup_cells_per_block;
+            uint64_t gc = ctx.gate_cursor, lc = ctx.lookup_cursor;
+            bool zero_loaded = ctx.zero_loaded;
+            frames.resize(n);
+            std::vector<hsw_frame_shape> fss(n);
+            size_t ob = 0;
+            for (size_t i = 0; i < n && rc == HSW_OK; i++) {
+                rc = hsw_frame_query(&ctx.shape, max_variable_byte_sizes[cur_hash_idx + i], is_input_range_check ? 1 : 0, &fss[i]);
+                if (rc != HSW_OK) break;
+                hsw_frame_desc &d = frames[i];
+                AssignedHashResult &r = results[i];
+                d.input_len = input_lens[i];
+                d.first_block = b0 + ob;
+                d.n_blocks = (uint32_t)plans[i].max_variable_round;
+                d.num_round = (uint32_t)plans[i].num_round;
+                d.precomputed_round = (uint32_t)plans[i].precomputed_round;
+                d.is_input_range_check = is_input_range_check ? 1u : 0u;
+                r.prologue_cell = d.prologue_cell = gc;      gc += fss[i].prologue_cells;
+                r.prologue_lookup = d.prologue_lookup = lc;  lc += fss[i].prologue_lookups;
+                d.zero_cell = ~0ull;
+                if (!zero_loaded) { d.zero_cell = gc++; zero_loaded = true; }   // compression.rs:34 of the first block
+                r.block_cell = gc;                           gc += (uint64_t)d.n_blocks * G;
+                r.block_lookup = lc;                         lc += (uint64_t)d.n_blocks * LK;
+                r.epilogue_cell = d.epilogue_cell = gc;      gc += fss[i].epilogue_cells;
+                r.epilogue_lookup = d.epilogue_lookup = lc;  lc += fss[i].epilogue_lookups;
+                r.end_cell = gc;
+                ob += d.n_blocks;
+            }
+            if (rc == HSW_OK && (gc > ctx.gate_capacity || lc > ctx.lookup_capacity)) rc = HSW_ERR_INVALID_ARG;
+            ob = 0;
+            for (size_t i = 0; i < n && rc == HSW_OK;) {
+                size_t j = i + 1;                            // run [i, j) of equally sized digests
+                while (j < n && frames[j].n_blocks == frames[i].n_blocks) j++;
+                const size_t nb = frames[i].n_blocks, run_blocks = nb * (j - i);
+                const uint64_t cursor = ctx.num_limb_sum + (uint64_t)ob * ctx.shape.limb_calls_per_block;
+                const uint64_t row_shift = cursor / ncols;
+                hsw_witness_args a{};
+                a.d_blocks = d_blk + 64 * ob;
+                a.d_pre_states = d_pre + 8 * ob;
+                a.n_blocks = run_blocks;
+                a.spread_cursor0 = cursor;
+                a.d_gate = static_cast<uint8_t *>(ctx.d_gate) + (size_t)results[i].block_cell * cb;
+                a.d_chip_dense = static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb;
+                a.d_chip_spread = static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb;
+                a.chip_col_stride = ctx.chip_col_stride;
+                a.d_next_states = d_next + 8 * ob;
+                a.d_lookup = static_cast<uint8_t *>(ctx.d_lookup) + (size_t)results[i].block_lookup * cb;
+                a.flags = ctx.repr_flags;
+                a.frame_every = nb;
+                a.frame_cells = fss[i].epilogue_cells + fss[i].prologue_cells;
+                a.frame_lookups = fss[i].epilogue_lookups + fss[i].prologue_lookups;
+                hsw_pack_plan plan{};
+                if (ctx.max_rows) {
+                    // column breaks relative to this launch's first cell; breaks before it are pure offsets
+                    const uint64_t base = results[i].block_cell;
+                    plan.n_breaks = (uint32_t)ctx.break_cell.size();
+                    for (size_t k = 0; k < ctx.break_cell.size(); k++) {
+                        plan.break_cell[k] = ctx.break_cell[k] > base ? ctx.break_cell[k] - base : 0;
+                        plan.break_gap[k] = ctx.break_gap[k];
+                    }
+                    a.pack = &plan;
+                }
+                rc = hsw_witness_blocks_ex(ctx.engine, &a);
+                ob += run_blocks;
+                i = j;
+            }
+            if (rc == HSW_OK) {
+                hsw_pack_plan plan{};
+                plan.n_breaks = (uint32_t)ctx.break_cell.size();
+                for (size_t k = 0; k < ctx.break_cell.size(); k++) {
+                    plan.break_cell[k] = ctx.break_cell[k];
+                    plan.break_gap[k] = ctx.break_gap[k];
+                }
+                rc = hsw_witness_frames(ctx.engine, frames.data(), n, ctx.d_blocks, ctx.d_pre_states, ctx.d_next_states,
+                                        ctx.d_gate, ctx.d_lookup, ctx.max_rows ? &plan : nullptr, ctx.repr_flags);
+            }
+            if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
+        }
+        if (rc != HSW_OK) break;
+        if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        he = hipStreamSynchronize(stream);
+    } while (0);
+    if (d_off) (void)hipFree(d_off);
+    if (rc != HSW_OK) return rc;
+    if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+
+    // ---- results: the "select state #target_round" rule (lib.rs:294-310) ----
+    off = 0;
+    for (size_t i = 0; i < n; i++) {
+        AssignedHashResult &r = results[i];
+        const DigestPlan &pl = plans[i];
+        r.input_len = input_lens[i];
+        r.input_bytes = pl.blocks;
+        r.first_block = b0 + off;
+        r.n_blocks = pl.max_variable_round;
+        r.spread_cursor0 = ctx.num_limb_sum + (uint64_t)off * ctx.shape.limb_calls_per_block;
+        r.num_round = pl.num_round;
+        r.target_round = pl.target_round;
+        uint32_t sel[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // output_h_out starts as zero cells (lib.rs:294-295)
+        if (pl.target_round == 0) std::memcpy(sel, pl.init_state, 32);                 // candidate 0
+        else if (pl.target_round <= pl.max_variable_round)
+            std::memcpy(sel, &h_next[8 * (off + pl.target_round - 1)], 32);            // candidate target_round
+        for (int w = 0; w < 8; w++) {                           // lib.rs:311-341 big-endian bytes
+            r.output_bytes[4 * w] = (uint8_t)(sel[w] >> 24);
+            r.output_bytes[4 * w + 1] = (uint8_t)(sel[w] >> 16);
+            r.output_bytes[4 * w + 2] = (uint8_t)(sel[w] >> 8);
+            r.output_bytes[4 * w + 3] = (uint8_t)sel[w];
+        }
+        off += pl.max_variable_round;
+    }
+    ctx.blocks_done += batch_blocks;
+    if (ctx.whole) {
+        ctx.gate_cursor = new_gate_cursor;
+        ctx.lookup_cursor = new_lookup_cursor;
+        ctx.zero_loaded = ctx.zero_loaded || batch_blocks != 0;
+    }
+    ctx.num_limb_sum += (uint64_t)batch_blocks * ctx.shape.limb_calls_per_block;   // spread.rs:228
+    cur_hash_idx += n;                                                             // lib.rs:347
+    return HSW_OK;
+}
+
+}  // namespace hsw
+
+// ------------------------------------------------------------------- C ABI
+struct hsw_gadget {
+    hsw::Sha256DynamicConfig cfg;
+    hsw::Context *ctx = nullptr;
+    std::vector<hsw::AssignedHashResult> results;   // one per digest so far (input_bytes kept for queries)
+};
+
+extern "C" {
+
+int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                       size_t max_variable_byte_size, uint8_t *blocks_out, uint32_t init_state_out[8],
+                       hsw_digest_info *info) {
+    hsw::DigestPlan plan;
+    const int rc = hsw::digest_prepare(input, input_len, precomputed_input_len, max_variable_byte_size, &plan);
+    if (rc != HSW_OK) return rc;
+    if (blocks_out && !plan.blocks.empty()) std::memcpy(blocks_out, plan.blocks.data(), plan.blocks.size());
+    if (init_state_out) std::memcpy(init_state_out, plan.init_state, 32);
+    if (info) {
+        info->num_round = plan.num_round;
+        info->precomputed_round = plan.precomputed_round;
+        info->target_round = plan.target_round;
+        info->n_blocks = plan.max_variable_round;
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                      int is_input_range_check, hsw_gadget **out) {
+    return hsw_gadget_create_ex(e, max_variable_byte_sizes, n_hashes, is_input_range_check, 0, out);
+}
+
+int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                         int is_input_range_check, uint32_t flags, hsw_gadget **out) {
+    if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
+    if (flags & ~HSW_GADGET_WHOLE_DIGEST) return HSW_ERR_INVALID_ARG;
+    *out = nullptr;
+    hsw_shape s;
+    int rc = hsw_engine_shape(e, &s);
+    if (rc != HSW_OK) return rc;
+    hsw_gadget *g = new (std::nothrow) hsw_gadget();
+    if (!g) return HSW_ERR_NOMEM;
+    std::vector<size_t> sizes(max_variable_byte_sizes, max_variable_byte_sizes + n_hashes);
+    rc = hsw::Sha256DynamicConfig::configure(sizes, s.num_bits_lookup, s.num_advice_columns,
+                                             is_input_range_check != 0, &g->cfg);
+    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0);
+    if (rc != HSW_OK) { delete g; return rc; }
+    *out = g;
+    return HSW_OK;
+}
+
+void hsw_gadget_destroy(hsw_gadget *g) {
+    if (!g) return;
+    delete g->ctx;
+    delete g;
+}
+
+static void fill_result(const hsw::AssignedHashResult &r, hsw_hash_result *o) {
+    o->input_len = r.input_len;
+    o->first_block = r.first_block;
+    o->n_blocks = r.n_blocks;
+    o->spread_cursor0 = r.spread_cursor0;
+    o->num_round = r.num_round;
+    o->target_round = r.target_round;
+    std::memcpy(o->output_bytes, r.output_bytes, 32);
+    o->prologue_cell = r.prologue_cell; o->block_cell = r.block_cell;
+    o->epilogue_cell = r.epilogue_cell; o->end_cell = r.end_cell;
+    o->prologue_lookup = r.prologue_lookup; o->block_lookup = r.block_lookup;
+    o->epilogue_lookup = r.epilogue_lookup;
+}
+
+int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs, const size_t *input_lens,
+                            const size_t *precomputed_input_lens, hsw_hash_result *results) {
+    if (!g || !results) return HSW_ERR_INVALID_ARG;
+    std::vector<hsw::AssignedHashResult> rs(n);
+    const int rc = g->cfg.digest_batch(*g->ctx, n, inputs, input_lens, precomputed_input_lens, rs.data());
+    if (rc != HSW_OK) return rc;
+    for (size_t i = 0; i < n; i++) {
+        fill_result(rs[i], &results[i]);
+        g->results.push_back(std::move(rs[i]));
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                      hsw_hash_result *result) {
+    return hsw_gadget_digest_batch(g, 1, &input, &input_len, &precomputed_input_len, result);
+}
+
+int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
+    if (!g || !view) return HSW_ERR_INVALID_ARG;
+    view->d_gate = g->ctx->d_gate;
+    view->d_chip_dense = g->ctx->d_chip_dense;
+    view->d_chip_spread = g->ctx->d_chip_spread;
+    view->d_next_states = g->ctx->d_next_states;
+    view->chip_col_stride = g->ctx->chip_col_stride;
+    view->blocks_done = g->ctx->blocks_done;
+    view->capacity_blocks = g->ctx->capacity_blocks;
+    view->num_limb_sum = g->ctx->num_limb_sum;
+    view->cur_hash_idx = g->cfg.cur_hash_idx;
+    view->gate_cells = g->ctx->gate_cursor;
+    view->gate_capacity = g->ctx->gate_capacity;
+    view->d_lookup = g->ctx->d_lookup;
+    view->lookup_cells = g->ctx->lookup_cursor;
+    view->lookup_capacity = g->ctx->lookup_capacity;
+    view->max_rows = g->ctx->max_rows;
+    view->columns = g->ctx->columns;
+    return HSW_OK;
+}
+
+int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len) {
+    if (!g || hash_idx >= g->results.size()) return HSW_ERR_INVALID_ARG;
+    const std::vector<uint8_t> &b = g->results[hash_idx].input_bytes;
+    if (len) *len = b.size();
+    if (out) {
+        if (cap < b.size()) return HSW_ERR_INVALID_ARG;
+        if (!b.empty()) std::memcpy(out, b.data(), b.size());
+    }
+    return HSW_OK;
+}
+
+int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    const int rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
+    if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
+    return rc;
+}
+
+int hsw_gadget_reset(hsw_gadget *g) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    const int rc = hsw_engine_synchronize(g->ctx->engine);
+    if (rc != HSW_OK) return rc;
+    hsw::Context &c = *g->ctx;
+    c.blocks_done = 0;
+    c.num_limb_sum = 0;                 // spread.rs:70-71
+    c.gate_cursor = c.lookup_cursor = 0;
+    c.zero_loaded = false;
+    g->cfg.cur_hash_idx = 0;            // lib.rs:66
+    g->results.clear();
+    return HSW_OK;
+}
+
+int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    g->ctx->position(cell, column, row);
+    return HSW_OK;
+}
+
+int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) {
+    if (!g || (repr & ~HSW_REPR_MASK) || repr == HSW_REPR_MASK) return HSW_ERR_INVALID_ARG;
+    if (g->ctx->whole && (repr & HSW_REPR_COMPACT64)) return HSW_ERR_UNSUPPORTED;   // frames hold full-width cells
+    if (g->ctx->blocks_done != 0 && hsw_cell_bytes(repr) != hsw_cell_bytes(g->ctx->repr_flags))
+        return HSW_ERR_INVALID_ARG;               // the cell size of a context's streams cannot change midway
+    g->ctx->repr_flags = repr;
+    return HSW_OK;
+}
+
+}  // extern "C"

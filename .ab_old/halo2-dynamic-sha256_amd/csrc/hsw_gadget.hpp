@@ -1,0 +1,129 @@
+// hsw_gadget.hpp -- host-side mirror of the reference's gadget front-end.
+//
+// Mirrors, by name and argument meaning, reference src/lib.rs:
+//   AssignedHashResult            lib.rs:31-36
+//   Sha256DynamicConfig           lib.rs:38-45
+//     ::configure                 lib.rs:49-69
+//     ::digest                    lib.rs:71-349
+//     ::new_context               lib.rs:351-360
+//     ::load                      lib.rs:366-368  (spread table, spread.rs:165-194)
+// What differs is only where the per-block work happens: the block loop of
+// lib.rs:180-238 becomes ONE hsw_witness_blocks call (HIP) for all blocks of
+// a digest -- or of a whole batch of digests.
+//
+// SURVEY 8 f4 -- the cells digest() itself allocates around the block loop
+// (length constraints lib.rs:122-151, inputs :162-178, is_equal/select :294-310,
+// output bytes :311-341) -- are emitted by a context created with
+// HSW_GADGET_WHOLE_DIGEST (hsw_frame.hpp / hsw_frame_kernel, assumption A4);
+// without it only their *values* are produced (AssignedHashResult).
+#ifndef HSW_GADGET_HPP
+#define HSW_GADGET_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/hsw.h"
+
+namespace hsw {
+
+// Value-level result of lib.rs:77-160 for one message.
+struct DigestPlan {
+    std::vector<uint8_t> blocks;   // padded_inputs[precomputed_input_len..]: max_variable_byte_size bytes
+    uint32_t init_state[8];        // INIT_STATE after compress256 over the precomputed prefix (lib.rs:153-160)
+    size_t num_round = 0;          // lib.rs:80-84
+    size_t precomputed_round = 0;  // lib.rs:93
+    size_t target_round = 0;       // num_round - precomputed_round (lib.rs:147-151): index into the state list
+    size_t max_variable_round = 0; // lib.rs:87: compressions synthesised, always the maximum
+};
+
+// lib.rs:77-117,153-160.  Returns HSW_OK or the status the reference's
+// assert!/debug_assert! maps to (HSW_ERR_SHAPE / HSW_ERR_TOO_LARGE).
+int digest_prepare(const uint8_t *input, size_t input_byte_size, size_t precomputed_input_len,
+                   size_t max_variable_byte_size, DigestPlan *plan);
+
+// lib.rs:31-36 on values, plus where this hash's streams live.
+struct AssignedHashResult {
+    uint64_t input_len = 0;              // assigned_input_byte_size (lib.rs:124-125)
+    std::vector<uint8_t> input_bytes;    // assigned_input_bytes (lib.rs:170-173): the padded variable part
+    uint8_t output_bytes[32] = {0};      // lib.rs:311-341
+    size_t first_block = 0;              // index of this hash's first block in the context's streams
+    size_t n_blocks = 0;                 // max_variable_byte_size / 64
+    uint64_t spread_cursor0 = 0;         // SpreadConfig.num_limb_sum when this digest started
+    size_t num_round = 0, target_round = 0;
+    // whole-digest contexts: where the sections of this digest start (cells)
+    uint64_t prologue_cell = 0, block_cell = 0, epilogue_cell = 0, end_cell = 0;
+    uint64_t prologue_lookup = 0, block_lookup = 0, epilogue_lookup = 0;
+};
+
+class Context;
+
+class Sha256DynamicConfig {
+  public:
+    std::vector<size_t> max_variable_byte_sizes;   // lib.rs:40
+    size_t cur_hash_idx = 0;                       // lib.rs:43
+    uint32_t num_bits_lookup = 8;                  // SpreadConfig (spread.rs:24-25)
+    uint32_t num_advice_columns = 2;
+    bool is_input_range_check = false;             // lib.rs:44 (the 8-bit range checks are halo2-base cells: emitted
+                                                   // by whole-digest contexts only)
+
+    // lib.rs:49-69.  HSW_ERR_SHAPE if a size is not a multiple of 64 (lib.rs:57-59)
+    // or the spread shape is invalid (spread.rs:37).
+    static int configure(const std::vector<size_t> &max_variable_byte_sizes, uint32_t num_bits_lookup,
+                         uint32_t num_advice_columns, bool is_input_range_check, Sha256DynamicConfig *out);
+
+    // lib.rs:351-360: a context sized for every hash this config will assign.
+    // whole_digest: also lay out digest()'s own cells (HSW_GADGET_WHOLE_DIGEST)
+    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false) const;
+
+    // lib.rs:71-349.  precomputed_input_len = 0 is the reference's None.
+    int digest(Context &ctx, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+               AssignedHashResult *result);
+    // n consecutive digest() calls with one kernel launch; results[i] as if called in order.
+    int digest_batch(Context &ctx, size_t n, const uint8_t *const *inputs, const size_t *input_lens,
+                     const size_t *precomputed_input_lens, AssignedHashResult *results);
+
+    // lib.rs:366-368 -> spread.rs:165-194: the (dense, spread) lookup table rows.
+    std::vector<std::pair<uint64_t, uint64_t>> load() const;
+};
+
+// The Region-owning context of lib.rs:351-360, re-imagined for HBM: it owns the
+// device buffers the streams are written to and SpreadConfig's mutable cursor.
+class Context {
+  public:
+    ~Context();
+    hsw_engine *engine = nullptr;
+    hsw_shape shape{};
+    size_t capacity_blocks = 0;      // sum(max_variable_byte_sizes) / 64
+    size_t blocks_done = 0;
+    uint64_t num_limb_sum = 0;       // SpreadConfig.num_limb_sum (spread.rs:26), starts at 0 (spread.rs:70)
+    size_t chip_col_stride = 0;      // rows per chip column buffer
+    void *d_gate = nullptr;          // capacity_blocks * G cells
+    void *d_chip_dense = nullptr;    // ncols * chip_col_stride cells
+    void *d_chip_spread = nullptr;
+    uint32_t *d_next_states = nullptr;   // capacity_blocks * 8
+    uint8_t *d_blocks = nullptr;         // staging: capacity_blocks * 64
+    uint32_t *d_pre_states = nullptr;    // capacity_blocks * 8
+    uint32_t *d_init_states = nullptr;   // one per hash in flight
+    size_t init_capacity = 0;
+    uint32_t repr_flags = HSW_REPR_CANONICAL;
+    // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
+    // digest, back to back) and d_lookup the lookup-advice stream next to it
+    bool whole = false;
+    bool zero_loaded = false;        // Context.zero_cell (first load_zero: compression.rs:34 of the first block)
+    uint64_t gate_cursor = 0, gate_capacity = 0;       // cells
+    void *d_lookup = nullptr;
+    uint64_t lookup_cursor = 0, lookup_capacity = 0;
+    // FlexGate column image (set_columns): d_gate is `columns` advice columns of max_rows cells;
+    // stream cell i sits at i + the gaps of all breaks at or before i (assumption A3-iii)
+    uint64_t max_rows = 0, columns = 0;
+    std::vector<uint64_t> break_cell, break_gap;
+    // Lay the whole-digest stream out as FlexGate (Vertical) advice columns of max_rows usable rows.
+    // Only before the first digest.  HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns.
+    int set_columns(const std::vector<size_t> &max_variable_byte_sizes, bool is_input_range_check, uint64_t max_rows);
+    // (column, row) of stream cell i
+    void position(uint64_t cell, uint64_t *column, uint64_t *row) const;
+};
+
+}  // namespace hsw
+#endif

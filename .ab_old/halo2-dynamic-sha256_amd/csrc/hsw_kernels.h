@@ -1,0 +1,65 @@
+// hsw_kernels.h -- internal launch interface between the C ABI (hsw_api.cpp)
+// and the gfx950 kernels (hsw_expand.hpp, hsw_kernels.hip).  Not part of the public boundary.
+#ifndef HSW_KERNELS_H
+#define HSW_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hsw {
+
+enum : uint32_t {
+    HSW_K_MONTGOMERY = 1u,   // mirrors HSW_REPR_MONTGOMERY
+    HSW_K_SKIP_GATE = 2u,    // mirrors HSW_SKIP_GATE
+    HSW_K_SKIP_CHIP = 4u,    // mirrors HSW_SKIP_CHIP
+    HSW_K_COMPACT = 8u,      // HSW_REPR_COMPACT64: 8-byte cells
+    HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
+};
+enum { HSW_K_MAX_BREAKS = 16 };
+
+struct ExpandParams {
+    const uint8_t *blocks;        // n_blocks * 64 bytes
+    const uint32_t *pre_states;   // n_blocks * 8
+    void *gate;                   // n_blocks * G cells of 32 B
+    void *chip_dense;             // ncols columns, chip_col_stride cells apart
+    void *chip_spread;
+    uint32_t *next_states;        // n_blocks * 8, may be null
+    size_t n_blocks;
+    size_t chip_col_stride;       // cells
+    uint64_t cursor0;             // SpreadConfig.num_limb_sum before block 0
+    uint32_t ncols;               // num_advice_columns
+    uint32_t flags;               // HSW_K_*
+    uint32_t parts;               // waves per block: 1, 2, 4, 8 or 16
+    void *lookup;                 // n_blocks * LOOKUP_CELLS cells (internals mode), may be null
+    // FlexGate column packing: gate cell i is written at i + sum of break_gap[k] over break_cell[k] <= i
+    uint32_t n_breaks;
+    uint64_t break_cell[HSW_K_MAX_BREAKS];
+    uint64_t break_gap[HSW_K_MAX_BREAKS];
+    // whole-digest streams (internals mode): after every frame_every blocks the gate stream skips
+    // frame_cells cells and the lookup stream frame_lookups cells (a digest's epilogue and the
+    // next digest's prologue, written by hsw_frame_kernel); frame_every = 0: off
+    uint64_t frame_every, frame_cells, frame_lookups;
+};
+
+// limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count
+// this build has no instantiation for.
+// tile = cells per tile row: 32 (64 units per wave), 64 (32 units, parts >= 2) or
+// 128 (16 units, parts >= 4).
+hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t stream);
+hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_per_message,
+                        const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
+
+hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
+                            const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
+hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
+
+struct FrameDesc;   // hsw_frame.hpp
+struct FrameBreaks;
+// d_inv_tbl: k^-1 mod p for k = 0..(largest n_blocks), 4 x u64 each, in the output representation
+hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
+                         const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
+                         const FrameBreaks &brk, bool montgomery, hipStream_t stream);
+
+}  // namespace hsw
+#endif

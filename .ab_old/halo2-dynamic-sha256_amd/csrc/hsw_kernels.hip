@@ -1,0 +1,116 @@
+// hsw_kernels.hip -- chain pre-pass, calibration fill and launch dispatch.
+// The expansion kernel template lives in hsw_expand.hpp and is instantiated per
+// table width in hsw_expand_l{1,2,4,8,16}.hip (parallel compilation).
+#include "hsw_expand.hpp"
+
+namespace hsw {
+
+// Plain SHA-256 chain of one message: writes the pre-state of each of its
+// blocks (what makes blocks independent for the expansion; lib.rs:188,236).
+DEV void chain_message(const uint8_t *blocks, size_t first_blk, size_t nblk, const u32 *init, u32 *pre_states) {
+    u32 st[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[i] = init ? init[i] : IV256[i];
+    for (size_t j = 0; j < nblk; j++) {
+        const size_t blk = first_blk + j;
+        const u32 *bw = reinterpret_cast<const u32 *>(blocks + 64 * blk);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pre_states[8 * blk + i] = st[i];
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32(bw[i]);
+        u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                const u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                const u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+            }
+            const u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+            const u32 chv = (e & f) ^ (~e & g);
+            const u32 t1 = h + S1 + chv + K256[t] + w[t & 15];
+            const u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+            const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+            const u32 t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+        st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+    }
+}
+
+// One thread per message, uniform blocks per message (hsw.h hsw_sha256_chain).
+__global__ __launch_bounds__(64) void hsw_chain_kernel(const uint8_t *blocks, size_t n_messages,
+                                                       size_t bpm, const u32 *init_states,
+                                                       u32 *pre_states) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_messages) return;
+    chain_message(blocks, m * bpm, bpm, init_states ? init_states + 8 * m : nullptr, pre_states);
+}
+
+// Ragged variant: message m owns blocks [offsets[m], offsets[m+1]) (gadget front-end:
+// hashes of one circuit may have different max_variable_byte_sizes, lib.rs:40,86).
+__global__ __launch_bounds__(64) void hsw_chain_var_kernel(const uint8_t *blocks, size_t n_messages,
+                                                           const u32 *offsets, const u32 *init_states,
+                                                           u32 *pre_states) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_messages) return;
+    chain_message(blocks, offsets[m], offsets[m + 1] - offsets[m],
+                  init_states ? init_states + 8 * m : nullptr, pre_states);
+}
+
+// Plain streaming fill, 16 B per lane, grid-stride: the practical HBM write
+// ceiling the expand kernel is compared against (bench.py "calibrated").
+__global__ __launch_bounds__(256) void hsw_fill_kernel(uint4 *dst, size_t n16, uint4 v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = v;
+}
+
+hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    uint4 v; v.x = 0x01010101u; v.y = 0; v.z = 0; v.w = 0;
+    hipLaunchKernelGGL(hsw_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<uint4 *>(dst), n16, v);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ launch
+template <int L> hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream);
+extern template hipError_t launch_expand_L<1>(const ExpandParams &, int, hipStream_t);
+extern template hipError_t launch_expand_L<2>(const ExpandParams &, int, hipStream_t);
+extern template hipError_t launch_expand_L<4>(const ExpandParams &, int, hipStream_t);
+extern template hipError_t launch_expand_L<8>(const ExpandParams &, int, hipStream_t);
+extern template hipError_t launch_expand_L<16>(const ExpandParams &, int, hipStream_t);
+
+hipError_t launch_expand(const ExpandParams &p, int limbs, int tile, hipStream_t stream) {
+    switch (limbs) {
+        case 1: return launch_expand_L<1>(p, tile, stream);
+        case 2: return launch_expand_L<2>(p, tile, stream);
+        case 4: return launch_expand_L<4>(p, tile, stream);
+        case 8: return launch_expand_L<8>(p, tile, stream);
+        case 16: return launch_expand_L<16>(p, tile, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t bpm,
+                        const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream) {
+    if (n_messages == 0 || bpm == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_messages + 63) / 64);
+    hipLaunchKernelGGL(hsw_chain_kernel, dim3(grid), dim3(64), 0, stream, blocks, n_messages, bpm,
+                       init_states, pre_states);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
+                            const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream) {
+    if (n_messages == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_messages + 63) / 64);
+    hipLaunchKernelGGL(hsw_chain_var_kernel, dim3(grid), dim3(64), 0, stream, blocks, n_messages, offsets,
+                       init_states, pre_states);
+    return hipGetLastError();
+}
+
+}  // namespace hsw

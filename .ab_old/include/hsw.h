@@ -1,0 +1,437 @@
+/*
+ * hsw.h -- C ABI of the MI355X SHA-256 witness engine ("halo2 sha witness").
+ *
+ * This is the drop-in boundary for the hot path of zhmolly/halo2-dynamic-sha256:
+ * the reference has NO FFI of its own (it is plain Rust calling halo2-base), so
+ * the boundary is new and sits exactly where `Sha256DynamicConfig::digest`
+ * calls `sha256_compression` once per 64-byte block:
+ *
+ *     reference src/lib.rs:180-189          the block loop (caller)
+ *     reference src/compression.rs:19-25    sha256_compression(ctx, range,
+ *                                           spread_config, bytes[64], pre_state[8])
+ *     reference src/spread.rs:196-233       spread_limb (chip column placement)
+ *
+ * A Rust shim keeps `Sha256DynamicConfig`'s surface, pads/chains on the host,
+ * calls hsw_witness_blocks() once for all blocks of a digest (or a batch of
+ * digests) and replays the returned streams into `Context`/`Region`
+ * (INTEGRATION.md shows the `extern "C"` block).
+ *
+ * Streams (DESIGN.md "Streams"):
+ *   gate cells   per block G cells (hsw_shape.gate_cells_per_block; 66,308 at
+ *                the reference's configuration), in the order the reference
+ *                issues halo2-base gate calls, 4 cells per add/neg/mul_add gate
+ *                and 1 per load_witness.
+ *   chip columns the SpreadConfig advice columns denses[c] / spreads[c]
+ *                (spread.rs:20-21): limb call #n (counted from
+ *                SpreadConfig.num_limb_sum) lands in column n % ncols at row
+ *                n / ncols (spread.rs:202-231).
+ *   next states  8 u32 words per block (compression.rs:197-212).
+ * One cell = 32 bytes = one BN254 scalar-field element, 4 little-endian 64-bit
+ * limbs, canonical (HSW_REPR_CANONICAL) or Montgomery (HSW_REPR_MONTGOMERY,
+ * the in-memory form of halo2curves' Fr) form; both are built.
+ * Beyond the block loop: in HSW_MODE_HALO2_INTERNALS the engine also emits the
+ * cells halo2-base / digest() allocate around it ("placement adaptor", "digest
+ * frame" below), up to the literal advice-column image of the whole region.
+ *
+ * All entry points return an int status (HSW_OK = 0); nothing unwinds across
+ * the ABI.  Shape violations that the reference would `assert!`/`debug_assert!`
+ * on (lib.rs:57-59,89-90; spread.rs:37; compression.rs:26-27) are hard errors.
+ */
+#ifndef HSW_H
+#define HSW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSW_ABI_VERSION 2
+
+/* ---- status codes ---- */
+#define HSW_OK                 0
+#define HSW_ERR_INVALID_ARG    1   /* NULL / misaligned / inconsistent argument */
+#define HSW_ERR_SHAPE          2   /* 16 % num_bits_lookup != 0, ncols == 0, max % 64 != 0 ... */
+#define HSW_ERR_NO_DEVICE      3   /* no usable gfx950 device / HIP runtime */
+#define HSW_ERR_HIP            4   /* a HIP call failed; see hsw_last_error() */
+#define HSW_ERR_UNSUPPORTED    5   /* valid request this build does not implement */
+#define HSW_ERR_TOO_LARGE      6   /* message does not fit max_variable_byte_size (lib.rs:90) */
+#define HSW_ERR_NOMEM          7
+
+/* ---- flags for hsw_witness_blocks ---- */
+#define HSW_REPR_CANONICAL     0u  /* cells hold the canonical integer, LE limbs */
+#define HSW_REPR_MONTGOMERY    1u  /* cells hold x*2^256 mod p (halo2curves Fr memory form) */
+#define HSW_REPR_COMPACT64    16u  /* transport form: 8-byte cells holding the low 64 bits of the canonical
+                                      value.  Every cell of the path fits 64 bits except the field negations
+                                      of ch (compression.rs:320-335; 256 cells per block at fixed positions,
+                                      hsw_neg_cells): those hold x where the cell's value is -x = p - x.
+                                      4x fewer bytes for PCIe-bound consumers; buffers are sized with
+                                      hsw_cell_bytes(flags) = 8 instead of 32 */
+#define HSW_REPR_MASK          (1u | 16u)
+#define HSW_SKIP_GATE          2u  /* do not write the gate stream (d_gate may be NULL) */
+#define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
+
+#define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only: pin the caller's output buffers
+                                      (hipHostRegister) for the duration of the call */
+
+#define HSW_CELL_BYTES         32u
+
+typedef struct hsw_engine hsw_engine;
+
+/* Shape of the streams for SpreadConfig::configure(num_bits_lookup,
+ * num_advice_columns) (spread.rs:32-74).  All counts are per 64-byte block. */
+typedef struct hsw_shape {
+    uint32_t num_bits_lookup;        /* 16 % it == 0 (spread.rs:37) */
+    uint32_t num_advice_columns;     /* >= 1 */
+    uint32_t limbs_per_spread;       /* 16 / num_bits_lookup (spread.rs:84) */
+    uint32_t cells_per_spread;       /* gate cells of one SpreadConfig::spread call */
+    uint32_t cells_per_state_spread; /* state_to_spread_u32 (compression.rs:215-246) */
+    uint32_t cells_per_sigma;        /* sigma_generic (compression.rs:702-882) */
+    uint32_t cells_per_ch;           /* compression.rs:297-405 */
+    uint32_t cells_per_maj;          /* compression.rs:460-519 */
+    uint32_t cells_per_sched_step;   /* one idx of compression.rs:57-96 */
+    uint32_t cells_per_round;        /* one idx of compression.rs:125-196 */
+    /* offsets (in cells) of the six regions of one block's gate stream */
+    uint32_t off_words;              /* compression.rs:31-47   16 x 16 cells */
+    uint32_t off_msg_spread;         /* compression.rs:53-56   16 state_to_spread_u32 */
+    uint32_t off_sched;              /* compression.rs:57-96   48 steps */
+    uint32_t off_state_spread;       /* compression.rs:109-115 6 state_to_spread_u32 */
+    uint32_t off_rounds;             /* compression.rs:125-196 64 rounds */
+    uint32_t off_feed;               /* compression.rs:197-212 8 x 10 cells */
+    uint32_t gate_cells_per_block;   /* G */
+    uint32_t spread_calls_per_block; /* 2,060 */
+    uint32_t limb_calls_per_block;   /* spread_calls * limbs_per_spread (cursor advance) */
+    uint32_t chip_cells_per_block;   /* 2 * limb_calls_per_block */
+    uint64_t algorithmic_bytes_per_block; /* (G + chip cells) * 32 + 64 + 32 + 32 */
+    uint32_t mode;                   /* HSW_MODE_* this shape was computed for */
+    uint32_t lookup_cells_per_block; /* entries of the lookup-advice column per block (3,184) */
+    uint32_t gate_calls_per_block;   /* halo2-base assign_region calls per block (the tape length) */
+    uint32_t reserved_;
+} hsw_shape;
+
+/* ---- engine modes ---- */
+#define HSW_MODE_DEFAULT          0u
+/* Also emit the cells halo2-base itself allocates inside the path -- the 4-cell
+ * inner product [limb0, limb1, 2^16, a] of every range_check(a, 32) (760 per
+ * block => G = 69,348) -- and make the lookup-advice column stream available
+ * (what RangeConfig::finalize copies, lib.rs:469: 3,184 cells per block).
+ * These follow halo2-lib v0.2.x (DESIGN.md assumption A3); the fork the
+ * reference pins is not in its tree, so A3 is unpinned.  8-bit spread table only. */
+#define HSW_MODE_HALO2_INTERNALS  1u
+
+/* Fill *out for the given SpreadConfig parameters.  Pure host arithmetic. */
+int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out);
+int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode,
+                       hsw_shape *out);
+
+/* SpreadConfig::load (spread.rs:165-194): the 2^num_bits_lookup rows
+ * (i, spread(i)) of the lookup table, as u64 values.  Either output may be NULL. */
+int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out);
+
+/* Bytes per cell for a flags word: 8 with HSW_REPR_COMPACT64, else 32. */
+uint32_t hsw_cell_bytes(uint32_t flags);
+/* Block-relative gate-stream indices of the cells that hold a field negation
+ * (4 per round, compression.rs:320-335), ascending; needed to decode
+ * HSW_REPR_COMPACT64.  out may be NULL to query the count (256). */
+int hsw_neg_cells(const hsw_shape *shape, uint32_t *out, size_t cap, size_t *n);
+
+/* Number of rows every chip column buffer must hold for n_blocks blocks whose
+ * first limb call is #spread_cursor0: buffer row 0 is absolute chip row
+ * spread_cursor0 / ncols.  Returns 0 on a bad shape. */
+uint64_t hsw_chip_rows(const hsw_shape *shape, uint64_t spread_cursor0, uint64_t n_blocks);
+
+/* Engine bound to one HIP device and stream (hip_stream: a hipStream_t, or
+ * NULL for the device's default stream).  One engine per host thread/stream;
+ * calls on one engine are issued asynchronously in order on that stream. */
+int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
+                      uint32_t num_advice_columns, hsw_engine **out);
+int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
+                         uint32_t num_advice_columns, uint32_t mode, hsw_engine **out);
+void hsw_engine_destroy(hsw_engine *e);
+int hsw_engine_shape(const hsw_engine *e, hsw_shape *out);
+int hsw_engine_synchronize(hsw_engine *e);
+
+/* Replaces n calls of sha256_compression (compression.rs:19-213).
+ *
+ *   d_blocks      n*64 message bytes            (device memory)
+ *   d_pre_states  n*8 u32 pre-state words       (device memory)
+ *   spread_cursor0  SpreadConfig.num_limb_sum before the first block
+ *                 (spread.rs:26,202); block j starts at cursor0 + j*limb_calls_per_block
+ *   d_gate        n*G cells (device memory); must be 16-byte aligned and should be
+ *                 32-byte (cell) aligned: at 16 mod 32 every canonical cell straddles
+ *                 two sectors and the launch runs ~45 % slower.  Any cell-aligned
+ *                 position is fine -- the kernel realigns its write-out to 128-byte
+ *                 lines (a few % slower than a line-aligned stream)
+ *   d_chip_dense / d_chip_spread
+ *                 ncols columns each; column c starts at base + c*chip_col_stride
+ *                 cells; hsw_chip_rows() rows are written per column (cells of
+ *                 the first/last row that belong to neighbouring calls are left
+ *                 untouched when the cursor is not a multiple of ncols)
+ *   d_next_states n*8 u32                       (device memory, may be NULL)
+ *   flags         HSW_REPR_* | HSW_SKIP_*
+ *
+ * Asynchronous on the engine's stream. */
+int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d_pre_states,
+                       size_t n_blocks, uint64_t spread_cursor0, void *d_gate,
+                       void *d_chip_dense, void *d_chip_spread, size_t chip_col_stride,
+                       uint32_t *d_next_states, uint32_t flags);
+
+/* ------------------------------------------------------------------------
+ * Placement adaptor: from streams to FlexGate advice columns.
+ * halo2-lib v0.2.x FlexGate (Vertical strategy) fills ONE advice column after
+ * another: every assign_region call of `len` cells goes to the current column
+ * at the current row, or -- if row + len >= max_rows -- to row 0 of the next
+ * column (assumption A3).  So advice columns are the linear gate stream with a
+ * gap of unused tail rows at every column break.  hsw_pack_plan_query computes
+ * the breaks for n_blocks blocks whose first cell lands at `start_row` of some
+ * column; hsw_witness_blocks_ex applies them while writing.
+ * ------------------------------------------------------------------------ */
+#define HSW_MAX_BREAKS 16
+typedef struct hsw_pack_plan {
+    uint32_t n_breaks;
+    uint32_t columns_touched;            /* 1 + n_breaks */
+    uint64_t break_cell[HSW_MAX_BREAKS]; /* linear stream index of the first cell after break k */
+    uint64_t break_gap[HSW_MAX_BREAKS];  /* unused tail rows of the column that break k closes */
+    uint64_t span_cells;                 /* cells from the first written one to one past the last, gaps included */
+    uint64_t end_row;                    /* row after the last cell in the last column (advice_alloc.1) */
+} hsw_pack_plan;
+int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_row, uint64_t max_rows,
+                        hsw_pack_plan *out);
+/* The assign_region call lengths of one block (1 or 4 each), in stream order:
+ * the tape a shim walks to replay the stream into halo2-base.  lens_out may be
+ * NULL to query the count. */
+int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls);
+
+typedef struct hsw_witness_args {
+    const uint8_t *d_blocks;       /* as hsw_witness_blocks */
+    const uint32_t *d_pre_states;
+    size_t n_blocks;
+    uint64_t spread_cursor0;
+    void *d_gate;                  /* where stream cell 0 lands: column base + start_row cells; columns are
+                                      max_rows cells apart, so hsw_pack_plan.span_cells cells are addressed */
+    void *d_chip_dense, *d_chip_spread;
+    size_t chip_col_stride;
+    uint32_t *d_next_states;
+    void *d_lookup;                /* n_blocks * lookup_cells_per_block cells (HSW_MODE_HALO2_INTERNALS), or NULL */
+    uint32_t flags;                /* HSW_REPR_* | HSW_SKIP_* */
+    const hsw_pack_plan *pack;     /* NULL = plain linear stream */
+    /* Whole-digest streams (HSW_MODE_HALO2_INTERNALS; see "digest frame" below): the blocks are
+     * those of consecutive digests of frame_every blocks each, and between the block streams of two
+     * digests the gate stream skips frame_cells cells and the lookup stream frame_lookups cells (one
+     * digest's epilogue + the next one's prologue, written by hsw_witness_frames).  0 = off. */
+    uint64_t frame_every, frame_cells, frame_lookups;
+} hsw_witness_args;
+int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args);
+
+/* Plain SHA-256 chain pre-pass (what makes the blocks of one message
+ * independent; lib.rs:188,236): message m has blocks_per_message consecutive
+ * blocks in d_blocks; its first pre-state is d_init_states[m*8..] (NULL = the
+ * FIPS IV, compression.rs:1003-1012).  Writes the pre-state of every block to
+ * d_pre_states (n_messages*blocks_per_message*8 u32).  Asynchronous. */
+int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
+                     size_t blocks_per_message, const uint32_t *d_init_states,
+                     uint32_t *d_pre_states);
+
+/* Host delivery: inputs and outputs are HOST memory.  Stages the inputs H2D, then
+ * expands chunks of 128 blocks on the engine's stream into two device staging
+ * slots while the previous chunk drains D2H on a second stream (kernel || copy
+ * overlap), and synchronizes.  Any output pointer may be NULL (stream skipped).
+ * Fastest with pinned output buffers (hsw_host_alloc, or HSW_HOST_REGISTER);
+ * PCIe-bound either way: 2.39 MB per block.  (If spread_cursor0 is not a
+ * multiple of num_advice_columns the call falls back to one unpipelined pass.) */
+int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t *pre_states,
+                            size_t n_blocks, uint64_t spread_cursor0, void *gate,
+                            void *chip_dense, void *chip_spread, size_t chip_col_stride,
+                            uint32_t *next_states, uint32_t flags);
+
+/* Pinned (page-locked) host memory for the buffers of hsw_witness_blocks_host. */
+int hsw_host_alloc(size_t bytes, void **out);
+void hsw_host_free(void *p);
+
+/* Duration in milliseconds of the most recent expansion kernel launched by
+ * hsw_witness_blocks on this engine, measured with HIP events recorded on the
+ * engine's stream around that launch.  Synchronizes on the stop event. */
+int hsw_last_kernel_ms(hsw_engine *e, float *ms);
+/* Enable/disable the per-launch event pair (off by default: no overhead). */
+int hsw_set_timing(hsw_engine *e, int enabled);
+
+/* The stream / device an engine was created on. */
+int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device);
+
+/* ------------------------------------------------------------------------
+ * Gadget front-end: the host side of Sha256DynamicConfig::digest
+ * (reference src/lib.rs:71-349) -- SHA-256 padding, zero fill up to the
+ * FIXED maximum size, prefix pre-hash, chaining, "select state #n" -- over
+ * the engine.  csrc/hsw_gadget.hpp holds the C++ class of the same name.
+ * ------------------------------------------------------------------------ */
+
+typedef struct hsw_digest_info {
+    size_t num_round;          /* real rounds incl. the precomputed ones (lib.rs:80-84) */
+    size_t precomputed_round;  /* lib.rs:93 */
+    size_t target_round;       /* num_round - precomputed_round (lib.rs:147-151) */
+    size_t n_blocks;           /* max_variable_byte_size / 64: compressions synthesised (lib.rs:87,180) */
+} hsw_digest_info;
+
+/* lib.rs:77-117,153-160 on the host, no GPU: pads `input`, returns the
+ * max_variable_byte_size bytes fed to the circuit (blocks_out, may be NULL)
+ * and the state after the precomputed prefix (init_state_out, may be NULL).
+ * HSW_ERR_SHAPE: max or precomputed length not a multiple of 64 (lib.rs:57-59,89);
+ * HSW_ERR_TOO_LARGE: padded message does not fit (lib.rs:90). */
+int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precomputed_input_len,
+                       size_t max_variable_byte_size, uint8_t *blocks_out,
+                       uint32_t init_state_out[8], hsw_digest_info *info);
+
+/* ------------------------------------------------------------------------
+ * Digest frame: the cells Sha256DynamicConfig::digest itself
+ * allocates around its block loop -- the prologue (lib.rs:122-178: lengths,
+ * is_less_than_safe, the initial state, the input bytes and their optional
+ * 8-bit range checks) and the epilogue (lib.rs:294-341: is_equal/select of the
+ * state after round #target, the 32 digest bytes with their range checks and
+ * recomposition).  With them the gate stream of one digest() call is, in order,
+ *     prologue | [the Context's zero cell, at its first use] | n_blocks x G | epilogue
+ * and the lookup-advice stream  prologue_lookups | n_blocks x 3,184 | 64.
+ * Cell layout of the halo2-base calls involved (mul, sub, is_zero, is_equal,
+ * select, is_less_than, range_check(.,8), the first load_zero) follows
+ * halo2-lib v0.2.x: ASSUMPTION A4 (csrc/hsw_frame.hpp), unpinned
+ * like A1-A3.  Needs an engine in HSW_MODE_HALO2_INTERNALS; canonical or
+ * Montgomery cells (a frame has full-width cells, so no COMPACT64).
+ * ------------------------------------------------------------------------ */
+typedef struct hsw_frame_shape {
+    uint64_t n_blocks;            /* max_variable_byte_size / 64 */
+    uint64_t prologue_cells;      /* 46 + max (+ 4*max with is_input_range_check) */
+    uint64_t epilogue_cells;      /* 76*(n_blocks + 1) + 288 */
+    uint64_t prologue_lookups;    /* 3 (+ 2*max) */
+    uint64_t epilogue_lookups;    /* 64 */
+    uint64_t prologue_calls;      /* assign_region calls (tape entries) */
+    uint64_t epilogue_calls;
+    uint64_t digest_cells;        /* prologue + n_blocks*G + epilogue; the zero cell is not counted */
+    uint64_t digest_lookups;
+} hsw_frame_shape;
+int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                    hsw_frame_shape *out);
+/* The assign_region call lengths of the prologue (section 0) or epilogue
+ * (section 1), like hsw_gate_tape.  lens_out may be NULL to query the count. */
+int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                   int section, uint8_t *lens_out, size_t cap, size_t *n_calls);
+
+typedef struct hsw_frame_desc {   /* one digest() call */
+    uint64_t input_len;           /* lib.rs:77 */
+    uint64_t first_block;         /* this digest's first block in d_blocks / d_pre_states / d_next_states */
+    uint64_t prologue_cell;       /* gate-stream cell index where its prologue starts */
+    uint64_t epilogue_cell;
+    uint64_t prologue_lookup;     /* lookup-stream cell indices */
+    uint64_t epilogue_lookup;
+    uint64_t zero_cell;           /* gate-stream index of the Context's zero cell if this digest is the
+                                     first to call load_zero in its Context, else UINT64_MAX */
+    uint32_t n_blocks;            /* >= 1 */
+    uint32_t num_round;           /* ceil((input_len + 9) / 64), lib.rs:80-84 (checked) */
+    uint32_t precomputed_round;   /* lib.rs:93; num_round - precomputed_round <= n_blocks (lib.rs:90) */
+    uint32_t is_input_range_check;
+} hsw_frame_desc;
+/* Writes the frames of n digests.  d_pre_states / d_next_states are the ones the
+ * block expansion read / wrote (the candidate states of lib.rs:296 are
+ * pre_states[first_block] and next_states[first_block .. first_block+n_blocks-1]);
+ * descs is HOST memory.  d_lookup may be NULL.  pack (may be NULL): FlexGate column
+ * breaks in the same absolute gate-stream indices as prologue_cell / epilogue_cell;
+ * a frame cell at stream index i is written at i + the gaps of all breaks <= i.
+ * Asynchronous on the engine's stream, ordered after earlier hsw_witness_blocks calls. */
+int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                       const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
+                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags);
+
+typedef struct hsw_gadget hsw_gadget;   /* Sha256DynamicConfig + its Context */
+
+typedef struct hsw_hash_result {        /* AssignedHashResult (lib.rs:31-36) on values */
+    uint64_t input_len;                 /* lib.rs:124-125 */
+    size_t first_block;                 /* this hash's first block in the gadget's streams */
+    size_t n_blocks;
+    uint64_t spread_cursor0;            /* SpreadConfig.num_limb_sum when this digest began */
+    size_t num_round, target_round;
+    uint8_t output_bytes[32];           /* lib.rs:311-341 */
+    /* HSW_GADGET_WHOLE_DIGEST only (else 0): where this digest's sections start in the
+     * gadget's gate / lookup streams, in cells */
+    uint64_t prologue_cell, block_cell, epilogue_cell, end_cell;
+    uint64_t prologue_lookup, block_lookup, epilogue_lookup;
+} hsw_hash_result;
+
+typedef struct hsw_gadget_view {
+    void *d_gate;                       /* capacity_blocks * G cells (device) */
+    void *d_chip_dense, *d_chip_spread; /* ncols columns, chip_col_stride cells apart, row 0 = chip row 0 */
+    uint32_t *d_next_states;
+    size_t chip_col_stride;
+    size_t blocks_done, capacity_blocks;
+    uint64_t num_limb_sum;              /* spread.rs:26 */
+    size_t cur_hash_idx;                /* lib.rs:43 */
+    /* HSW_GADGET_WHOLE_DIGEST: d_gate is ONE stream of gate_cells cells (of gate_capacity), the
+     * digests back to back with their frames; d_lookup the lookup-advice stream.  Else 0 / NULL. */
+    uint64_t gate_cells, gate_capacity;
+    void *d_lookup;
+    uint64_t lookup_cells, lookup_capacity;
+    uint64_t max_rows, columns;         /* hsw_gadget_set_columns: d_gate is columns x max_rows cells; else 0 */
+} hsw_gadget_view;
+
+/* Sha256DynamicConfig::configure (lib.rs:49-69) + new_context (lib.rs:351-360):
+ * allocates HBM for sum(max_variable_byte_sizes)/64 blocks of streams. */
+int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                      int is_input_range_check, hsw_gadget **out);
+/* flags: HSW_GADGET_WHOLE_DIGEST = also emit the digest frames (engine must be in
+ * HSW_MODE_HALO2_INTERNALS): the gadget's gate stream is then every advice cell the
+ * reference's digest() calls allocate, in allocation order. */
+#define HSW_GADGET_WHOLE_DIGEST 1u
+int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
+                         int is_input_range_check, uint32_t flags, hsw_gadget **out);
+void hsw_gadget_destroy(hsw_gadget *g);
+/* HSW_GADGET_WHOLE_DIGEST, before the first digest: lay the gate stream out as the
+ * FlexGate (Vertical) advice columns themselves -- column c = cells [c*max_rows,
+ * (c+1)*max_rows) of d_gate, every assign_region call placed by the v0.2.x rule
+ * `row + len >= max_rows -> next column` (assumption A3-iii), unassigned tail rows 0.
+ * max_rows = the gate's usable rows (RangeConfig.gate.max_rows, lib.rs:355).  The
+ * layout depends only on max_variable_byte_sizes, never on the messages.
+ * HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns. */
+int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns);
+/* Start the next synthesis pass with the same buffers and layout: every cursor back to
+ * its initial value (cur_hash_idx, num_limb_sum, the stream cursors, the Context's zero
+ * cell).  What the reference's harnesses do by cloning the config per synthesis
+ * (lib.rs:440, benches/digest.rs:78).  Waits for outstanding work on the engine. */
+int hsw_gadget_reset(hsw_gadget *g);
+/* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
+int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);
+/* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.
+ * Synchronous: returns once the streams of this hash are in HBM. */
+int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len,
+                      size_t precomputed_input_len, hsw_hash_result *result);
+/* n consecutive digest() calls as ONE kernel launch (results as if sequential). */
+int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs,
+                            const size_t *input_lens, const size_t *precomputed_input_lens,
+                            hsw_hash_result *results);
+int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view);
+/* AssignedHashResult.input_bytes of digest #hash_idx (the padded variable part). */
+int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len);
+/* HSW_REPR_CANONICAL (default) or HSW_REPR_MONTGOMERY for subsequent digests. */
+int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr);
+
+/* Synchronous device-to-host copy on the engine's stream (for callers that hold
+ * device pointers from hsw_gadget_streams but have no HIP binding of their own). */
+int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes);
+
+/* Calibration: overwrites `bytes` of d_buf with a plain 16-byte-per-lane
+ * streaming fill and returns its duration -- the practical HBM write ceiling
+ * of this device/allocation, which bench.py reports next to the 8 TB/s spec. */
+int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
+
+/* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
+ * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
+ * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
+ * (also 6416 = [16 rows][64 cells], the default of the compact form). */
+int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
+
+const char *hsw_strerror(int status);
+/* Detail of the last failure on this engine ("" if none); never NULL. */
+const char *hsw_last_error(const hsw_engine *e);
+uint32_t hsw_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSW_H */
