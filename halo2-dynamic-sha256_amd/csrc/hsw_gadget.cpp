@@ -615,6 +615,35 @@ int hsw_gadget_reset(hsw_gadget *g) {
     return HSW_OK;
 }
 
+int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) {
+    if (!g || hash_idx > g->cfg.max_variable_byte_sizes.size()) return HSW_ERR_INVALID_ARG;
+    int rc = hsw_engine_synchronize(g->ctx->engine);
+    if (rc != HSW_OK) return rc;
+    hsw::Context &c = *g->ctx;
+    size_t blocks = 0;
+    uint64_t gate = 0, lookup = 0;
+    for (size_t h = 0; h < hash_idx; h++) {
+        const size_t b = g->cfg.max_variable_byte_sizes[h];
+        blocks += b / 64;
+        if (c.whole) {
+            hsw_frame_shape fs;
+            rc = hsw_frame_query(&c.shape, b, g->cfg.is_input_range_check ? 1 : 0, &fs);
+            if (rc != HSW_OK) return rc;
+            gate += fs.digest_cells + (h == 0 ? 1 : 0);       // + the Context's zero cell, loaded by digest #0
+            lookup += fs.digest_lookups;
+        }
+    }
+    c.blocks_done = blocks;
+    c.num_limb_sum = (uint64_t)blocks * c.shape.limb_calls_per_block;       // spread.rs:228-231
+    c.gate_cursor = gate;
+    c.lookup_cursor = lookup;
+    c.zero_loaded = hash_idx > 0;
+    g->cfg.cur_hash_idx = hash_idx;
+    g->results.clear();
+    g->results.resize(hash_idx);        // keeps hash_idx -> result indexing of hsw_gadget_input_bytes
+    return HSW_OK;
+}
+
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) {
     if (!g) return HSW_ERR_INVALID_ARG;
     g->ctx->position(cell, column, row);

@@ -115,6 +115,13 @@ class Sha256DynamicConfig:
         self._ok(self.lib.hsw_gadget_reset(self.h))
         self._n = 0
 
+    def seek(self, hash_idx):
+        """Continue at digest #hash_idx as if the earlier ones had been assigned (their positions
+        follow from max_variable_byte_sizes alone): lets several GPUs share one circuit's digests."""
+        self._resolve_pending()
+        self._ok(self.lib.hsw_gadget_seek(self.h, hash_idx))
+        self._n = hash_idx
+
     def cell_position(self, cell):
         c, r = C.c_uint64(), C.c_uint64()
         self._ok(self.lib.hsw_gadget_cell_position(self.h, cell, C.byref(c), C.byref(r)))

@@ -395,6 +395,13 @@ int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns
  * cell).  What the reference's harnesses do by cloning the config per synthesis
  * (lib.rs:440, benches/digest.rs:78).  Waits for outstanding work on the engine. */
 int hsw_gadget_reset(hsw_gadget *g);
+/* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
+ * (cur_hash_idx, num_limb_sum, the gate / lookup stream cursors, the zero cell) takes the value it
+ * would have then.  All of them follow from max_variable_byte_sizes alone -- never from the
+ * messages -- so the digests of one circuit can be dealt to several GPUs (one gadget each, same
+ * configuration): rank r seeks to its first digest and assigns its share into the same positions
+ * the serial reference would use; no exchange is needed to agree on the layout. */
+int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx);
 /* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);
 /* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.

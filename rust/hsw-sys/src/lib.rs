@@ -220,6 +220,7 @@ extern "C" {
     pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
+    pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
     pub fn hsw_gadget_cell_position(g: *const hsw_gadget, cell: u64, column: *mut u64, row: *mut u64) -> c_int;
     pub fn hsw_frame_query(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                            out: *mut hsw_frame_shape) -> c_int;

@@ -283,3 +283,56 @@ def test_whole_digest_randomized_contexts(hsw, oracle, eng_int):
         assert np.array_equal(st["gate"], exp), (trial, sizes, [len(m) for m in msgs], pres, rc, batch, max_rows)
         assert np.array_equal(st["lookup"], ref["lookup"]), trial
         assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]]), trial
+
+
+@pytest.mark.parametrize("columns", [False, True])
+def test_seek_deals_one_circuit_to_two_gadgets(hsw, oracle, eng_int, columns):
+    """hsw_gadget_seek: two gadgets (two GPUs in production) with the same configuration assign
+    disjoint digests of one circuit into the positions the serial reference would use; the union of
+    their images is the single-gadget image.  No exchange is needed: positions depend on
+    max_variable_byte_sizes only."""
+    sizes = [128, 64, 192, 64]
+    msgs = [b"a" * 100, b"bc", bytes(range(150)), b""]
+    max_rows = 140000 if columns else None
+
+    def run(first, last):
+        cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+        if max_rows:
+            cfg.set_columns(max_rows)
+        if first:
+            cfg.seek(first)
+        res = cfg.digest_batch(msgs[first:last], [None] * (last - first))
+        # the gadget's view only covers what it has written; read the whole buffers
+        v = cfg.view()
+        n_gate = int(v.max_rows * v.columns) if max_rows else int(v.gate_capacity)
+
+        def grab(ptr, n_cells):
+            a = np.zeros((n_cells, 4), dtype=np.uint64)
+            cfg._ok(cfg.lib.hsw_download(eng_int.h, a.ctypes.data, ptr, n_cells * 32))
+            return a
+        out = dict(gate=grab(v.d_gate, n_gate), lookup=grab(v.d_lookup, int(v.lookup_capacity)),
+                   dense=grab(v.d_chip_dense, 2 * int(v.chip_col_stride)), res=res,
+                   end=(int(v.gate_cells), int(v.lookup_cells), int(v.num_limb_sum), int(v.cur_hash_idx)))
+        cfg.close()
+        return out
+
+    full = run(0, 4)
+    a, b = run(0, 2), run(2, 4)
+    assert b["end"] == full["end"]                                   # the cursors after the last digest agree
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    g_end = len(ref["gate"])
+    if not columns:
+        # linear stream: hipMalloc'd, so only the written ranges are defined -- compare those
+        cut = a["end"][0]
+        assert np.array_equal(a["gate"][:cut], ref["gate"][:cut])
+        assert np.array_equal(b["gate"][cut:g_end], ref["gate"][cut:g_end])
+    else:
+        # column image: zero-initialised, the two halves are disjoint
+        assert np.array_equal(a["gate"] | b["gate"], full["gate"])
+        assert not (a["gate"].any(axis=1) & b["gate"].any(axis=1)).any()
+    lc = a["end"][1]
+    assert np.array_equal(a["lookup"][:lc], ref["lookup"][:lc]) and np.array_equal(b["lookup"][lc:], ref["lookup"][lc:])
+    assert np.array_equal(a["dense"] | b["dense"], full["dense"])
+    for m, r in zip(msgs[2:], b["res"]):
+        assert r.output_bytes == hashlib.sha256(m).digest()
+    assert [r.prologue_cell for r in b["res"]] == [r.prologue_cell for r in full["res"][2:]]
