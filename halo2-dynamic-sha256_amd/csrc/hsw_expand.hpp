@@ -187,6 +187,10 @@ struct Em {
     static constexpr bool COMPACT = REPR_ == 2;
     static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
     static constexpr int STRIDE = T + 3;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
+    // Realigned write-out (flush_tile).  Free for the HBM-bound canonical kernels; the Montgomery kernels
+    // are issue-bound and pay ~4 % for it even on aligned streams, so they realign only in internals mode,
+    // where misaligned streams are the rule (digest frames, column images); compact cells never do.
+    static constexpr bool REALIGN = REPR_ == 0 || (REPR_ == 1 && RC_);
     u64 *row0;         // this lane's tile row (LDS), column 0
     u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
     u32 carry_neg;     // bit j: carried column j holds a field negation
@@ -256,7 +260,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
     const u32 lane = threadIdx.x;
     char *base = reinterpret_cast<char *>(em.out);
     const bool packed = em.brk1 != 0xffffffffu;          // wave-uniform; false unless a pack plan is in force
-    const u32 skew = em.skew;
+    const u32 skew = EM::REALIGN ? em.skew : 0u;
     // A skewed unit shares its first line with the previous unit's tail, which is written at the END of
     // the phase: the first 4 - skew cells of every unit but the wave's first are held back in em.head and
     // appended to the previous row's tail in the last flush, so that the shared line is completed within
@@ -446,7 +450,7 @@ DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u
     // realignment (flush_tile): only where every unit of the phase starts at the same offset within
     // a 128-byte line (unit_cells % 4 == 0: words, schedule steps, rounds -- 98 % of the cells)
     u32 skew = 0;
-    if constexpr (!EM::COMPACT) {
+    if constexpr (EM::REALIGN) {
         if ((unit_cells & 3u) == 0u) {
             u32 cl = em.cell_base;
             if (em.brk1 != 0xffffffffu) cl = packed_cell(em, cl);
@@ -550,7 +554,7 @@ DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_b
 template <int L, class EM, class C>
 DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base) {
     if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
-    else if (em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1, C::cn);      // the carried cells only
+    else if (EM::REALIGN && em.skew != 0u) flush_tile<EM, false>(em, 0u, C::fl, -1, -1, -1, -1, C::cn);   // the carried cells only
     flush_chip<L>(em, p, block_first_limb);
     if constexpr (EM::RC) flush_lookup(em, p, lookup_block_base);
 }
