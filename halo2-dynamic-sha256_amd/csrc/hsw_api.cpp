@@ -621,7 +621,9 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipHostGetDevicePointer", he);
     const bool mont = (flags & HSW_REPR_MONTGOMERY) != 0;
     he = hsw::launch_frames(d_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
-                            d_gate, d_lookup, brk, mont, e->stream);
+                            d_gate, d_lookup, brk,
+                            /* workgroups per digest: one per 4 blocks (256 input bytes each), at most 64 */
+                            (unsigned)(max_blocks / 4 < 1 ? 1 : (max_blocks / 4 > 64 ? 64 : max_blocks / 4)), mont, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_frame_kernel", he);
     he = hipEventRecord(slot.done, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);

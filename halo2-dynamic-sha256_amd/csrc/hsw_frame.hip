@@ -83,11 +83,15 @@ template <bool MONT>
 __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, const uint8_t *blocks,
                                                         const u32 *pre_states, const u32 *next_states,
                                                         const u64 *inv_tbl, uint4 *gate, uint4 *lookup,
-                                                        FrameBreaks brk) {
+                                                        FrameBreaks brk, u32 slices) {
     using namespace frame;
-    const FrameDesc d = descs[blockIdx.x];
+    // `slices` workgroups share one digest: slice 0 also writes the fixed cells, all of them stride
+    // through the input bytes and the candidate states (a 16 KiB digest has 82 k byte cells)
+    const u32 slice = blockIdx.x % slices;
+    const FrameDesc d = descs[blockIdx.x / slices];
     const Out<MONT> o{gate, lookup, &brk};
-    const u32 tid = threadIdx.x, nthreads = blockDim.x;
+    const u32 tid = threadIdx.x;
+    const u32 gtid = slice * blockDim.x + tid, nthreads = slices * blockDim.x;
     const u64 P0 = d.prologue_cell, E0 = d.epilogue_cell;
     const u32 N = d.n_blocks;
     const u64 max_bytes = (u64)N * 64u;
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
         const u64 shift_a = pad + 65536, shifted = shift_a - 64;
         const u64 limb0 = shifted & 0xffff, limb1 = shifted >> 16;              // limb1 = 0 <=> pad < 64
         const u64 z = limb1 == 0 ? 1 : 0;
-        if (tid < P_STATE) {
+        if (slice != 0u) {
+        } else if (tid < P_STATE) {
             u64 v = 0;
             switch (tid) {
                 case P_LEN: v = len; break;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
     }
 
     // ---- prologue, input bytes: lib.rs:170-178 ----
-    for (u64 i = tid; i < max_bytes; i += nthreads) {
+    for (u64 i = gtid; i < max_bytes; i += nthreads) {
         const u32 b = bytes[i];
         o.cell(P0 + P_BYTES + i, b);
         if (d.range_check_inputs)
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
 
     // ---- epilogue, state selection: lib.rs:294-310 ----
     // work item j: candidate n = j / 9; part 0 = is_equal(n, target), parts 1..8 = select of word part - 1
-    for (u32 j = tid; j < 9u * (N + 1); j += nthreads) {
+    for (u32 j = gtid; j < 9u * (N + 1); j += nthreads) {
         const u32 n = j / 9u, part = j % 9u;
         const u64 at = E0 + (u64)E_STATE * n;
         const bool sel = n == target;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
     }
 
     // ---- epilogue, digest bytes: lib.rs:311-341 ----
-    if (tid >= 128 && tid < 160) {
+    if (slice == 0u && tid >= 128 && tid < 160) {
         const u32 w = (tid - 128) / 4, idx = (tid - 128) % 4;
         const u32 word = target <= N ? state_word(target, w) : 0;
         const u64 at = E0 + (u64)E_STATE * (N + 1) + (u64)E_WORD * w;
@@ -193,17 +198,18 @@ __global__ __launch_bounds__(256) void hsw_frame_kernel(const FrameDesc *descs, 
 
 hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
                          const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
-                         const FrameBreaks &brk, bool montgomery, hipStream_t stream) {
+                         const FrameBreaks &brk, unsigned slices, bool montgomery, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const dim3 grid((unsigned)n), block(256);
+    if (slices == 0) slices = 1;
+    const dim3 grid((unsigned)(n * slices)), block(256);
     if (montgomery)
         hipLaunchKernelGGL(hsw_frame_kernel<true>, grid, block, 0, stream, d_descs, blocks, pre_states, next_states,
                            reinterpret_cast<const u64 *>(d_inv_tbl), reinterpret_cast<uint4 *>(gate),
-                           reinterpret_cast<uint4 *>(lookup), brk);
+                           reinterpret_cast<uint4 *>(lookup), brk, slices);
     else
         hipLaunchKernelGGL(hsw_frame_kernel<false>, grid, block, 0, stream, d_descs, blocks, pre_states, next_states,
                            reinterpret_cast<const u64 *>(d_inv_tbl), reinterpret_cast<uint4 *>(gate),
-                           reinterpret_cast<uint4 *>(lookup), brk);
+                           reinterpret_cast<uint4 *>(lookup), brk, slices);
     return hipGetLastError();
 }
 

@@ -130,6 +130,7 @@ Context::~Context() {
     (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
     (void)hipFree(d_init_states); (void)hipFree(d_lookup);
+    if (hp_blocks) (void)hipHostFree(hp_blocks);
 }
 
 int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
@@ -177,6 +178,20 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_blocks, nb * 64);
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_pre_states, nb * 32);
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_init_states, nh * 32);
+    if (he == hipSuccess) {
+        void *pin = nullptr, *dpin = nullptr;
+        he = hipHostMalloc(&pin, nb * 128, hipHostMallocMapped);
+        if (he == hipSuccess) {
+            c->hp_blocks = static_cast<uint8_t *>(pin);
+            he = hipHostGetDevicePointer(&dpin, pin, 0);
+        }
+        if (he == hipSuccess) {
+            c->hp_pre = reinterpret_cast<uint32_t *>(c->hp_blocks + nb * 64);
+            c->hp_next = reinterpret_cast<uint32_t *>(c->hp_blocks + nb * 96);
+            c->dp_blocks = static_cast<uint8_t *>(dpin);
+            c->dp_pre = reinterpret_cast<uint32_t *>(c->dp_blocks + nb * 64);
+        }
+    }
     if (he == hipSuccess) he = hipMemset(c->d_chip_dense, 0, col_bytes);
     if (he == hipSuccess) he = hipMemset(c->d_chip_spread, 0, col_bytes);
     if (he != hipSuccess) {
@@ -293,10 +308,13 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     // dependent kernel launch; a big batch uses hsw_chain_var_kernel, one lane per message.
     // Either way the witness cells -- and the next_states the digest is read from -- come
     // from the GPU.
+    // Such a small batch also skips the H2D copies: blocks and pre-states go into pinned, device-mapped
+    // host memory that the kernels read in place (96 bytes per block over PCIe).
     const bool host_chain = batch_blocks <= 2048;
-    std::vector<uint32_t> h_pre;
-    if (host_chain) {
-        h_pre.resize(batch_blocks * 8 ? batch_blocks * 8 : 1);
+    const size_t b0 = ctx.blocks_done;
+    if (host_chain && batch_blocks) {
+        std::memcpy(ctx.hp_blocks + 64 * b0, h_blocks.data(), batch_blocks * 64);
+        uint32_t *h_pre = ctx.hp_pre + 8 * b0;
         for (size_t i = 0; i < n; i++) {
             uint32_t st[8];
             std::memcpy(st, plans[i].init_state, 32);
@@ -314,26 +332,33 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     hsw_engine_stream(ctx.engine, reinterpret_cast<void **>(&stream), &device);
     DeviceScope ds(device);
     if (!ds.ok) return HSW_ERR_NO_DEVICE;
-    const size_t b0 = ctx.blocks_done;
-    uint8_t *d_blk = ctx.d_blocks + 64 * b0;
-    uint32_t *d_pre = ctx.d_pre_states + 8 * b0;
+    // Up to 32 blocks the expansion reads its 96 input bytes per block straight from the pinned staging
+    // (uncached PCIe reads: cheaper than two copies for a handful of waves, not beyond); the frame kernel
+    // reads every byte on its own, so whole-digest contexts always take the copies.
+    const bool zero_copy = host_chain && !ctx.whole && batch_blocks <= 32;
+    const uint8_t *in_blocks = zero_copy ? ctx.dp_blocks : ctx.d_blocks;        // bases, indexed by absolute block
+    const uint32_t *in_pre = zero_copy ? ctx.dp_pre : ctx.d_pre_states;
+    const uint8_t *d_blk = in_blocks + 64 * b0;
+    const uint32_t *d_pre = in_pre + 8 * b0;
     uint32_t *d_next = ctx.d_next_states + 8 * b0;
     uint32_t *d_off = nullptr;
-    std::vector<uint32_t> h_next(batch_blocks * 8 ? batch_blocks * 8 : 1);
+    uint32_t *h_next = ctx.hp_next + 8 * b0;                                     // pinned: the D2H below is asynchronous
     hipError_t he = hipSuccess;
     int rc = HSW_OK;
     std::vector<hsw_frame_desc> frames;
     uint64_t new_gate_cursor = ctx.gate_cursor, new_lookup_cursor = ctx.lookup_cursor;
     do {
         if (batch_blocks == 0) break;
-        if ((he = hipMemcpyAsync(d_blk, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-        if (host_chain) {
-            if ((he = hipMemcpyAsync(d_pre, h_pre.data(), batch_blocks * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-        } else {
+        if (host_chain && !zero_copy) {      // from pinned memory: both copies are asynchronous DMA
+            if ((he = hipMemcpyAsync(ctx.d_blocks + 64 * b0, ctx.hp_blocks + 64 * b0, batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+            if ((he = hipMemcpyAsync(ctx.d_pre_states + 8 * b0, ctx.hp_pre + 8 * b0, batch_blocks * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
+        }
+        if (!host_chain) {
+            if ((he = hipMemcpyAsync(ctx.d_blocks + 64 * b0, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
             if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
             if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
             if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-            if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, d_pre, stream)) != hipSuccess) break;
+            if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, ctx.d_pre_states + 8 * b0, stream)) != hipSuccess) break;
         }
         const size_t G = ctx.shape.gate_cells_per_block;
         const size_t cb = hsw_cell_bytes(ctx.repr_flags);
@@ -424,13 +449,13 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                     plan.break_cell[k] = ctx.break_cell[k];
                     plan.break_gap[k] = ctx.break_gap[k];
                 }
-                rc = hsw_witness_frames(ctx.engine, frames.data(), n, ctx.d_blocks, ctx.d_pre_states, ctx.d_next_states,
+                rc = hsw_witness_frames(ctx.engine, frames.data(), n, in_blocks, in_pre, ctx.d_next_states,
                                         ctx.d_gate, ctx.d_lookup, ctx.max_rows ? &plan : nullptr, ctx.repr_flags);
             }
             if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
         }
         if (rc != HSW_OK) break;
-        if ((he = hipMemcpyAsync(h_next.data(), d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        if ((he = hipMemcpyAsync(h_next, d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         he = hipStreamSynchronize(stream);
     } while (0);
     if (d_off) (void)hipFree(d_off);

@@ -106,6 +106,12 @@ class Context {
     uint32_t *d_pre_states = nullptr;    // capacity_blocks * 8
     uint32_t *d_init_states = nullptr;   // one per hash in flight
     size_t init_capacity = 0;
+    // small batches: pinned, device-mapped host staging the kernels read directly (no H2D copies) and
+    // the next states are copied back into (a truly asynchronous D2H): capacity_blocks * (64 + 32 + 32) bytes
+    uint8_t *hp_blocks = nullptr;        // host views ...
+    uint32_t *hp_pre = nullptr, *hp_next = nullptr;
+    uint8_t *dp_blocks = nullptr;        // ... and the device addresses of the same memory
+    uint32_t *dp_pre = nullptr;
     uint32_t repr_flags = HSW_REPR_CANONICAL;
     // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
     // digest, back to back) and d_lookup the lookup-advice stream next to it

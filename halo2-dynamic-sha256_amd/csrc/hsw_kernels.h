@@ -59,7 +59,7 @@ struct FrameBreaks;
 // d_inv_tbl: k^-1 mod p for k = 0..(largest n_blocks), 4 x u64 each, in the output representation
 hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
                          const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,
-                         const FrameBreaks &brk, bool montgomery, hipStream_t stream);
+                         const FrameBreaks &brk, unsigned slices, bool montgomery, hipStream_t stream);
 
 }  // namespace hsw
 #endif

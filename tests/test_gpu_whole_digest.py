@@ -35,6 +35,7 @@ CASES = [  # (messages, max sizes, precomputed, input range checks, one batch ca
     ([bytes(range(200))], [128], [128], False, True),             # precomputed prefix
     ([bytes(range(119)), b"xy", b"q" * 70], [128, 64, 128], None, False, True),   # three runs in one batch
     ([bytes([7] * 200)], [128], [192], False, True),              # target_round = 1 after 3 precomputed rounds
+    ([bytes(range(256)) * 14], [4096], None, True, True),         # 64 blocks: the frame kernel runs 16 workgroups
 ]
 
 
