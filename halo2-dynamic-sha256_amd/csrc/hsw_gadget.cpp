@@ -4,8 +4,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include "hsw_kernels.h"
 
@@ -30,7 +34,7 @@ inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 // What sha2::compress256 does for the precomputed prefix (lib.rs:160).  The
 // prefix is by definition NOT part of the circuit, so the reference hashes it
 // on the CPU too; this is not a fallback of the witness path.
-void plain_compress(uint32_t st[8], const uint8_t *block) {
+void plain_compress_scalar(uint32_t st[8], const uint8_t *block) {
     uint32_t w[64];
     for (int i = 0; i < 16; i++)
         w[i] = ((uint32_t)block[4 * i] << 24) | ((uint32_t)block[4 * i + 1] << 16) |
@@ -48,6 +52,61 @@ void plain_compress(uint32_t st[8], const uint8_t *block) {
     }
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// The same with the x86 SHA extensions (sha2 0.10.6 itself dispatches to them at run time): the plain
+// chain of a long digest is the only serial part of the path, 0.4 us per block in scalar code.
+// State lives as ABEF / CDGH, the operand order of sha256rnds2; a group of four rounds takes the four
+// message words + K in one register, and sha256msg1 / sha256msg2 compute the next four schedule words.
+__attribute__((target("sha,sse4.1,ssse3")))
+void plain_compress_shani(uint32_t st[8], const uint8_t *block) {
+    const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i tmp = _mm_loadu_si128(reinterpret_cast<const __m128i *>(&st[0]));        // d c b a (high .. low lane)
+    __m128i s1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(&st[4]));         // h g f e
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                                              // c d a b
+    s1 = _mm_shuffle_epi32(s1, 0x1B);                                                // e f g h
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                                        // a b e f
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                                             // c d g h
+    const __m128i abef_save = s0, cdgh_save = s1;
+    __m128i m[4];
+    for (int i = 0; i < 16; i++) {
+        if (i < 4) {
+            m[i] = _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(block + 16 * i)), bswap);
+        } else {
+            // W[4i..4i+3] from W[4i-16..], W[4i-12..], W[4i-8..], W[4i-4..]
+            __m128i x = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);              // W[t-16] + sigma0(W[t-15])
+            x = _mm_add_epi32(x, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));  // + W[t-7]
+            m[i & 3] = _mm_sha256msg2_epu32(x, m[(i + 3) & 3]);                      // + sigma1(W[t-2])
+        }
+        __m128i wk = _mm_add_epi32(m[i & 3], _mm_loadu_si128(reinterpret_cast<const __m128i *>(&K[4 * i])));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, wk);
+        wk = _mm_shuffle_epi32(wk, 0x0E);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, wk);
+    }
+    s0 = _mm_add_epi32(s0, abef_save);
+    s1 = _mm_add_epi32(s1, cdgh_save);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                                               // f e b a
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                                                // d c h g
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);                                             // d c b a
+    s1 = _mm_alignr_epi8(s1, tmp, 8);                                                // h g f e
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(&st[0]), s0);
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(&st[4]), s1);
+}
+bool have_shani() {
+    static const bool ok = [] {
+        if (std::getenv("HSW_NO_SHANI")) return false;      // tests: force the scalar code
+        __builtin_cpu_init();
+        return __builtin_cpu_supports("sha") != 0;
+    }();
+    return ok;
+}
+void plain_compress(uint32_t st[8], const uint8_t *block) {
+    if (have_shani()) plain_compress_shani(st, block);
+    else plain_compress_scalar(st, block);
+}
+#else
+void plain_compress(uint32_t st[8], const uint8_t *block) { plain_compress_scalar(st, block); }
+#endif
 
 struct DeviceScope {
     int prev = -1;

@@ -84,3 +84,32 @@ def test_prepare_property_random_shapes(hsw, oracle):
         assert info["n_blocks"] == max_blocks and info["precomputed_round"] == pre_blocks
 
     prop()
+
+
+def test_prefix_prehash_scalar_and_sha_extension_paths_agree():
+    """The host pre-hash of the precomputed prefix (lib.rs:153-160) uses the x86 SHA extensions when the
+    CPU has them; HSW_NO_SHANI forces the scalar code.  Both must give hashlib's state."""
+    import hashlib, os, subprocess, sys
+    code = r"""
+import importlib, sys, hashlib
+sys.path.insert(0, %r)
+hsw = importlib.import_module("halo2-dynamic-sha256_amd")
+msg = bytes((i * 7 + 3) %% 256 for i in range(1000))
+blocks, init, info = hsw.digest_prepare(msg, 512, 576)
+print(bytes(blocks).hex(), [int(x) for x in init], info["target_round"])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"HSW_NO_SHANI": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1]
+    # and against an independent SHA-256: finishing the hash from that state gives hashlib's digest
+    from oracle import oracle as O
+    msg = bytes((i * 7 + 3) % 256 for i in range(1000))
+    hexblocks, init, tr = outs[0].split(" ", 1)[0], eval(outs[0].split(" ", 1)[1].rsplit(" ", 1)[0]), int(outs[0].rsplit(" ", 1)[1])
+    st = __import__("numpy").array(init, dtype="uint32")
+    blocks = bytes.fromhex(hexblocks)
+    for r in range(tr):
+        st = O.plain_compress(st, __import__("numpy").frombuffer(blocks[64 * r: 64 * r + 64], dtype="uint8"))
+    assert b"".join(int(x).to_bytes(4, "big") for x in st) == hashlib.sha256(msg).digest()
