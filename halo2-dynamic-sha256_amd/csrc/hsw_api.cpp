@@ -25,6 +25,7 @@ struct hsw_engine {
     hsw_shape shape{};
     int limbs = 2;
     int parts = 0;             // waves per block; 0 = choose from the batch size
+    int split = -1;            // one phase per wave (32 waves per block): -1 = for tiny batches, 0 = never, 1 = always
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
     uint32_t mode = HSW_MODE_DEFAULT;
     bool timing = false;
@@ -308,6 +309,11 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         e->parts = (int)value;
         return HSW_OK;
     }
+    if (std::strcmp(name, "split") == 0) {
+        if (value < -1 || value > 1) return set_err(e, HSW_ERR_INVALID_ARG, "split must be -1 (auto), 0 or 1");
+        e->split = (int)value;
+        return HSW_OK;
+    }
     if (std::strcmp(name, "tile") == 0) {
         if (value != 0 && value != 32 && value != 64 && value != 128 && value != 6416)
             return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 0 (auto), 32, 64 or 128");
@@ -431,6 +437,12 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
         p.frame_lookups = args->frame_lookups;
         const int tile = choose_tile(e, flags);
         p.parts = (uint32_t)choose_parts(e, n_blocks, tile, flags);
+        // tiny batches are latency-bound: 32 waves per block, each running ONE phase program (all of
+        // them resident at once; measured better up to 32 blocks); only where no explicit split of the work was asked for
+        if (e->limbs == 2 && (e->split == 1 || (e->split < 0 && e->parts == 0 && n_blocks <= 32))) {
+            p.parts = 32;
+            p.flags |= hsw::HSW_K_SPLIT;
+        }
         if (args->pack) {
             // breaks are given in call-relative stream indices; this launch starts at cell done*G
             for (uint32_t k = 0; k < args->pack->n_breaks; k++) {

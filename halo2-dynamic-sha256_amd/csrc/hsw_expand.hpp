@@ -848,6 +848,22 @@ DEV auto maj_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     return g_mul_add(c10, em, m_hi_odd, 1u << 16, m_lo_odd, out);    // :512-517
 }
 
+// Which waves of a block expand which phase.  Normally every wave takes a share of every phase.  In
+// split mode (tiny batches, 32 waves per block) each wave runs ONE phase program -- rounds on 16 waves,
+// schedule steps on 8, words / message spreads / state spreads / feed-forward on 2 each -- so the
+// latency of a launch is the chain plus the longest program (a round), not the sum of all six.
+enum { PH_WORDS = 0, PH_MSG, PH_SCHED, PH_STATE, PH_ROUNDS, PH_FEED };
+DEV bool phase_window(bool split, int phase, u32 part, u32 parts, u32 &wpart, u32 &wparts) {
+    if (!split) { wpart = part; wparts = parts; return true; }
+    const u32 first = phase == PH_ROUNDS ? 0u : phase == PH_SCHED ? 16u : phase == PH_WORDS ? 24u
+                    : phase == PH_MSG ? 26u : phase == PH_STATE ? 28u : 30u;
+    const u32 count = phase == PH_ROUNDS ? 16u : phase == PH_SCHED ? 8u : 2u;
+    const bool in = part >= first && part < first + count;
+    wpart = in ? part - first : 0u;
+    wparts = count;
+    return in;
+}
+
 // --------------------------------------------------------------- the kernel
 // T = tile width in cells (contiguous run per row = 32*T bytes), R = tile rows =
 // units one wave expands per phase; a block needs parts >= 64/R waves.
@@ -915,9 +931,15 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
 
     // ---- every lane pulls the seeds of its units into registers -------------
     auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };   // a..d = sA[3..0], e..h = sE[3..0]
-    const u32 u16_ = lane_unit(part, parts, 16), us = lane_unit(part, parts, 48);
-    const u32 ust = lane_unit(part, parts, 6), ur = lane_unit(part, parts, 64), uf = lane_unit(part, parts, 8);
-    const u32 seed_word = sW[u16_];
+    const bool split = (p.flags & HSW_K_SPLIT) != 0u;        // parts == 32 then
+    u32 wp[6], wn[6];
+    bool in_phase[6];
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) in_phase[ph] = phase_window(split, ph, part, parts, wp[ph], wn[ph]);
+    const u32 uw = lane_unit(wp[PH_WORDS], wn[PH_WORDS], 16), um = lane_unit(wp[PH_MSG], wn[PH_MSG], 16);
+    const u32 us = lane_unit(wp[PH_SCHED], wn[PH_SCHED], 48), ust = lane_unit(wp[PH_STATE], wn[PH_STATE], 6);
+    const u32 ur = lane_unit(wp[PH_ROUNDS], wn[PH_ROUNDS], 64), uf = lane_unit(wp[PH_FEED], wn[PH_FEED], 8);
+    const u32 seed_word = sW[uw], seed_word_msg = sW[um];
     const u32 seed_w2 = sW[us + 14], seed_w15 = sW[us + 1], seed_w7 = sW[us + 9], seed_w16 = sW[us];
     const u32 seed_state = pre_word(ust < 3 ? ust : ust + 1);
     const u32 seed_a = sA[ur + 3], seed_b = sA[ur + 2], seed_c = sA[ur + 1], seed_d = sA[ur];
@@ -963,7 +985,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u64 blk_limb0 = p.cursor0 + (u64)blk * (u64)LY::LIMB_CALLS;   // first limb call of this block
 
     // ---- words: compression.rs:31-47, 16 units of 4 mul_add ----------------
-    if (phase_begin(em, part, parts, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
+    if (in_phase[PH_WORDS] && phase_begin(em, wp[PH_WORDS], wn[PH_WORDS], 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
         const u32 word = seed_word;                          // bytes[3 - idx] * 2^(8 idx) + sum
         const u32 b0 = word & 0xffu, b1 = (word >> 8) & 0xffu, b2 = (word >> 16) & 0xffu, b3 = word >> 24;
         const u32 s0 = b0, s1 = s0 | (b1 << 8), s2 = s1 | (b2 << 16);
@@ -975,13 +997,13 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     }
 
     // ---- 16 x state_to_spread_u32(W[i]): compression.rs:53-56 --------------
-    if (phase_begin(em, part, parts, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
-        auto c1 = state_to_spread<L>(CurStart{}, em, seed_word);
+    if (in_phase[PH_MSG] && phase_begin(em, wp[PH_MSG], wn[PH_MSG], 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
+        auto c1 = state_to_spread<L>(CurStart{}, em, seed_word_msg);
         phase_end<L>(c1, em, p, blk_limb0, lk_blk);
     }
 
     // ---- schedule: compression.rs:57-96, 48 units --------------------------
-    if (phase_begin(em, part, parts, 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED,
+    if (in_phase[PH_SCHED] && phase_begin(em, wp[PH_SCHED], wn[PH_SCHED], 48, LY::SCHED, LY::OFF_SCHED, LY::CALL_SCHED, LY::CALLS_SCHED,
                     LY::LK_OFF_SCHED, LY::LK_SCHED)) {
         const u32 w2 = seed_w2, w15 = seed_w15, w7 = seed_w7, w16 = seed_w16;   // W[idx-2], [idx-15], [idx-7], [idx-16]
         u32 term1, term3, new_w;
@@ -997,13 +1019,13 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     }
 
     // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 ----
-    if (phase_begin(em, part, parts, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
+    if (in_phase[PH_STATE] && phase_begin(em, wp[PH_STATE], wn[PH_STATE], 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
         auto c1 = state_to_spread<L>(CurStart{}, em, seed_state);
         phase_end<L>(c1, em, p, blk_limb0, lk_blk);
     }
 
     // ---- 64 rounds: compression.rs:125-196 ---------------------------------
-    if (phase_begin(em, part, parts, 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND,
+    if (in_phase[PH_ROUNDS] && phase_begin(em, wp[PH_ROUNDS], wn[PH_ROUNDS], 64, LY::ROUND, LY::OFF_ROUNDS, LY::CALL_ROUNDS, LY::CALLS_ROUND,
                     LY::LK_OFF_ROUNDS, LY::LK_ROUND)) {
         const u32 a = seed_a, b = seed_b, c = seed_c, d = seed_d;
         const u32 e = seed_e, f = seed_f, g = seed_g, h = seed_h;
@@ -1030,7 +1052,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     }
 
     // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
-    if (phase_begin(em, part, parts, 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
+    if (in_phase[PH_FEED] && phase_begin(em, wp[PH_FEED], wn[PH_FEED], 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
         u64 s;
         u32 lo;
         auto c1 = g_add(CurStart{}, em, seed_fx, seed_fy, s);
@@ -1042,7 +1064,8 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
 // ------------------------------------------------------------------ launch
 template <int L, int T, int R, bool RC>
 static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
-    if (p.parts * (unsigned)R < 64u) return hipErrorInvalidValue;    // every unit needs a row
+    if ((p.flags & HSW_K_SPLIT) ? (p.parts != 32u || R < 8) : (p.parts * (unsigned)R < 64u))
+        return hipErrorInvalidValue;                                 // every unit needs a row
     const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
     if (p.flags & HSW_K_MONTGOMERY)
         hipLaunchKernelGGL((hsw_expand_kernel<L, T, R, 1, RC>), grid, block, 0, stream, p);

@@ -15,6 +15,7 @@ enum : uint32_t {
     HSW_K_SKIP_CHIP = 4u,    // mirrors HSW_SKIP_CHIP
     HSW_K_COMPACT = 8u,      // HSW_REPR_COMPACT64: 8-byte cells
     HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
+    HSW_K_SPLIT = 32u,       // 32 waves per block, each running one phase program (tiny batches: latency)
 };
 enum { HSW_K_MAX_BREAKS = 16 };
 

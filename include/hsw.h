@@ -430,7 +430,9 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
 /* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
  * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
  * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
- * (also 6416 = [16 rows][64 cells], the default of the compact form). */
+ * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": one phase
+ * program per wave, 32 waves per block -- -1 = for batches of <= 32 blocks (default), 0 = never,
+ * 1 = always. */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 
 const char *hsw_strerror(int status);

@@ -297,6 +297,38 @@ def test_stream_not_line_aligned(engine_factory, oracle, hsw, shift, tile, parts
         eng.set_option("parts", 0)
 
 
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("tile", [0, 32, 64, 128])
+@pytest.mark.parametrize("flags_name", ["canonical", "montgomery", "compact"])
+def test_split_phase_mode_gives_identical_streams(engine_factory, oracle, hsw, split, tile, flags_name):
+    """"split": 32 waves per block, each running ONE phase program (what tiny batches use by default
+    for latency) -- against the ordinary partition and the oracle."""
+    N = hsw._native
+    flags = {"canonical": 0, "montgomery": N.HSW_REPR_MONTGOMERY, "compact": N.HSW_REPR_COMPACT64}[flags_name]
+    eng = engine_factory(8, 2)
+    eng.set_option("split", split)
+    eng.set_option("tile", tile)
+    try:
+        blocks, pre = _rand_inputs(5, 4242 + tile)
+        ref = oracle.Oracle(8, 2, check=True).witness_blocks(blocks, pre, cursor0=7)
+        got = _run_gpu(eng, blocks, pre, cursor0=7, flags=flags)
+        if flags_name == "compact":
+            g = got["gate"].view(np.uint64).reshape(-1)[: 5 * eng.G]
+            exp = ref["gate"][:, 0].copy()
+            neg = np.nonzero(ref["gate"][:, 1:].any(axis=1))[0]
+            exp[neg] = np.uint64(0x43e1f593f0000001) - exp[neg]
+            assert np.array_equal(g, exp)
+        else:
+            conv = oracle.to_montgomery if flags_name == "montgomery" else (lambda x: x)
+            assert np.array_equal(got["gate"].view(np.uint64), conv(ref["gate"]))
+            assert np.array_equal(got["dense"].view(np.uint64), conv(ref["dense"]))
+            assert np.array_equal(got["spread"].view(np.uint64), conv(ref["spread"]))
+        assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])
+    finally:
+        eng.set_option("split", -1)
+        eng.set_option("tile", 0)
+
+
 def test_huge_cursor_and_second_stream(hsw, oracle):
     """num_limb_sum beyond 2^32 (u64 row arithmetic) on an engine bound to a
     non-default HIP stream."""
