@@ -339,14 +339,17 @@ def main():
         cfg = hsw.Sha256DynamicConfig(eng, [1024] * 64, True)
         for _ in range(4):
             cfg.digest(m)
-        t1 = time.perf_counter()
+        tg = []
         for _ in range(50):
+            t1 = time.perf_counter()
             r = cfg.digest(m)
-        dtg = (time.perf_counter() - t1) / 50
+            tg.append(time.perf_counter() - t1)
+        dtg = float(np.median(tg))
         assert r.output_bytes == hashlib.sha256(m).digest()
         cfg.close()
         extra["config1_1KiB_message_16_blocks"]["gadget_digest_end_to_end"] = {
-            "ms_per_message": dtg * 1e3, "blocks_per_s": 16 / dtg}
+            "ms_per_message": dtg * 1e3, "blocks_per_s": 16 / dtg, "ms_mean": float(np.mean(tg)) * 1e3,
+            "ms_max": float(np.max(tg)) * 1e3, "slowest_iteration": int(np.argmax(tg))}
         # BASELINE configs[0], the reference's own bench circuit (benches/digest.rs:103-129): one 56-byte
         # message, max 1024 B, input range checks, k = 17 -- as the literal advice-column image of the whole
         # region (SURVEY 8 f2 + f4, assumptions A1-A4): 9 FlexGate columns x 131,063 rows + the lookup column
