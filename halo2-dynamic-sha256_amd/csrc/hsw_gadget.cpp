@@ -104,8 +104,10 @@ void plain_compress(uint32_t st[8], const uint8_t *block) {
     if (have_shani()) plain_compress_shani(st, block);
     else plain_compress_scalar(st, block);
 }
+bool host_sha_is_fast() { return have_shani(); }
 #else
 void plain_compress(uint32_t st[8], const uint8_t *block) { plain_compress_scalar(st, block); }
+bool host_sha_is_fast() { return false; }
 #endif
 
 struct DeviceScope {
@@ -360,16 +362,19 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         off += plans[i].max_variable_round;
     }
     h_offsets[n] = (uint32_t)off;
-    // The plain SHA chain (pre-state of every block, lib.rs:188,236) is the only serial
-    // part: ~4 us per block on one GPU lane, ~0.4 us on the host.  A small batch (one
-    // digest of the bench circuit is 16 blocks) is chained here, next to the prefix
-    // pre-hash the reference also does on the CPU (lib.rs:153-160), which saves a
-    // dependent kernel launch; a big batch uses hsw_chain_var_kernel, one lane per message.
-    // Either way the witness cells -- and the next_states the digest is read from -- come
-    // from the GPU.
-    // Such a small batch also skips the H2D copies: blocks and pre-states go into pinned, device-mapped
-    // host memory that the kernels read in place (96 bytes per block over PCIe).
-    const bool host_chain = batch_blocks <= 2048;
+    // The plain SHA chain (pre-state of every block, lib.rs:188,236) is the only serial part.  Chained
+    // on the host it sits next to the prefix pre-hash the reference also does on the CPU (lib.rs:153-160)
+    // and saves a dependent kernel launch; on the GPU (hsw_chain_var_kernel) every message has its own
+    // lane.  Either way the witness cells -- and the next_states the digest is read from -- come from the
+    // GPU.  Host-chained batches stage blocks and pre-states in pinned, device-mapped host memory.
+    // Which side chains: the host walks all blocks at ~0.1 us each (x86 SHA extensions; 0.4 us scalar), the
+    // GPU chains every message on its own lane at ~3.6 us per block plus a dependent launch.  Many short
+    // messages -> GPU; few long ones -> host.
+    size_t longest = 0;
+    for (size_t i = 0; i < n; i++) longest = plans[i].max_variable_round > longest ? plans[i].max_variable_round : longest;
+    const double t_host_us = (double)batch_blocks * (host_sha_is_fast() ? 0.1 : 0.4);
+    const double t_gpu_us = 15.0 + 3.6 * (double)longest;
+    const bool host_chain = t_host_us <= t_gpu_us;
     const size_t b0 = ctx.blocks_done;
     if (host_chain && batch_blocks) {
         std::memcpy(ctx.hp_blocks + 64 * b0, h_blocks.data(), batch_blocks * 64);
