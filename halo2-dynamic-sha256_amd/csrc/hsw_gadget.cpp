@@ -190,7 +190,7 @@ std::vector<std::pair<uint64_t, uint64_t>> Sha256DynamicConfig::load() const {
 Context::~Context() {
     (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
-    (void)hipFree(d_init_states); (void)hipFree(d_lookup);
+    (void)hipFree(d_init_states); (void)hipFree(d_offsets); (void)hipFree(d_lookup);
     if (hp_blocks) (void)hipHostFree(hp_blocks);
 }
 
@@ -239,6 +239,7 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_blocks, nb * 64);
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_pre_states, nb * 32);
     if (he == hipSuccess) he = hipMalloc((void **)&c->d_init_states, nh * 32);
+    if (he == hipSuccess) he = hipMalloc((void **)&c->d_offsets, (nh + 1) * sizeof(uint32_t));
     if (he == hipSuccess) {
         void *pin = nullptr, *dpin = nullptr;
         he = hipHostMalloc(&pin, nb * 128, hipHostMallocMapped);
@@ -405,7 +406,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     const uint8_t *d_blk = in_blocks + 64 * b0;
     const uint32_t *d_pre = in_pre + 8 * b0;
     uint32_t *d_next = ctx.d_next_states + 8 * b0;
-    uint32_t *d_off = nullptr;
+    uint32_t *d_off = ctx.d_offsets;
     uint32_t *h_next = ctx.hp_next + 8 * b0;                                     // pinned: the D2H below is asynchronous
     hipError_t he = hipSuccess;
     int rc = HSW_OK;
@@ -419,7 +420,6 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         }
         if (!host_chain) {
             if ((he = hipMemcpyAsync(ctx.d_blocks + 64 * b0, h_blocks.data(), batch_blocks * 64, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
-            if ((he = hipMalloc((void **)&d_off, (n + 1) * sizeof(uint32_t))) != hipSuccess) break;
             if ((he = hipMemcpyAsync(ctx.d_init_states, h_init.data(), n * 32, hipMemcpyHostToDevice, stream)) != hipSuccess) break;
             if ((he = hipMemcpyAsync(d_off, h_offsets.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) break;
             if ((he = launch_chain_var(d_blk, n, d_off, ctx.d_init_states, ctx.d_pre_states + 8 * b0, stream)) != hipSuccess) break;
@@ -522,7 +522,6 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         if ((he = hipMemcpyAsync(h_next, d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         he = hipStreamSynchronize(stream);
     } while (0);
-    if (d_off) (void)hipFree(d_off);
     if (rc != HSW_OK) return rc;
     if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
 

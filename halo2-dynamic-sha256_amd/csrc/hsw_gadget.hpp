@@ -105,6 +105,7 @@ class Context {
     uint8_t *d_blocks = nullptr;         // staging: capacity_blocks * 64
     uint32_t *d_pre_states = nullptr;    // capacity_blocks * 8
     uint32_t *d_init_states = nullptr;   // one per hash in flight
+    uint32_t *d_offsets = nullptr;       // first block of every hash in flight (+ 1): hsw_chain_var_kernel
     size_t init_capacity = 0;
     // small batches: pinned, device-mapped host staging the kernels read directly (no H2D copies) and
     // the next states are copied back into (a truly asynchronous D2H): capacity_blocks * (64 + 32 + 32) bytes
