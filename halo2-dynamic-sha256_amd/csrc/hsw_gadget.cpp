@@ -139,20 +139,31 @@ int digest_prepare(const uint8_t *input, size_t input_byte_size, size_t precompu
     const size_t precomputed_round = precomputed_input_len / one_round_size;  // lib.rs:93
     const size_t total = max_variable_byte_size + precomputed_input_len;
 
-    std::vector<uint8_t> padded(total, 0);                                    // lib.rs:98-117
-    if (input_byte_size) std::memcpy(padded.data(), input, input_byte_size);
-    size_t n = input_byte_size;
-    padded[n++] = 0x80;                                                       // lib.rs:99
-    n += zero_padding_byte_size;                                              // lib.rs:100-102
-    const uint64_t bitlen = 8ull * (uint64_t)input_byte_size;                 // lib.rs:103-108 (big-endian)
-    for (int i = 7; i >= 0; i--) padded[n++] = (uint8_t)(bitlen >> (8 * i));
-    if (n != num_round * one_round_size) return HSW_ERR_INVALID_ARG;          // lib.rs:110
-    if (n + remaining_byte_size != total) return HSW_ERR_INVALID_ARG;         // lib.rs:111-117
-
     std::memcpy(plan->init_state, INIT_STATE, sizeof INIT_STATE);             // lib.rs:155
-    for (size_t r = 0; r < precomputed_round; r++)                            // lib.rs:156-160
-        plain_compress(plan->init_state, padded.data() + r * one_round_size);
-    plan->blocks.assign(padded.begin() + (ptrdiff_t)precomputed_input_len, padded.end());   // lib.rs:170
+    const uint64_t bitlen = 8ull * (uint64_t)input_byte_size;                 // lib.rs:103-108 (big-endian)
+    if (precomputed_input_len == 0) {
+        // the common case: no prefix -- pad straight into the bytes fed to the circuit (lib.rs:98-117,170)
+        plan->blocks.assign(max_variable_byte_size, 0);
+        if (input_byte_size) std::memcpy(plan->blocks.data(), input, input_byte_size);
+        size_t n = input_byte_size;
+        plan->blocks[n++] = 0x80;                                             // lib.rs:99
+        n += zero_padding_byte_size;                                          // lib.rs:100-102
+        for (int i = 7; i >= 0; i--) plan->blocks[n++] = (uint8_t)(bitlen >> (8 * i));
+        if (n != num_round * one_round_size) return HSW_ERR_INVALID_ARG;      // lib.rs:110
+        if (n + remaining_byte_size != total) return HSW_ERR_INVALID_ARG;     // lib.rs:111-117
+    } else {
+        std::vector<uint8_t> padded(total, 0);                                // lib.rs:98-117
+        if (input_byte_size) std::memcpy(padded.data(), input, input_byte_size);
+        size_t n = input_byte_size;
+        padded[n++] = 0x80;                                                   // lib.rs:99
+        n += zero_padding_byte_size;                                          // lib.rs:100-102
+        for (int i = 7; i >= 0; i--) padded[n++] = (uint8_t)(bitlen >> (8 * i));
+        if (n != num_round * one_round_size) return HSW_ERR_INVALID_ARG;      // lib.rs:110
+        if (n + remaining_byte_size != total) return HSW_ERR_INVALID_ARG;     // lib.rs:111-117
+        for (size_t r = 0; r < precomputed_round; r++)                        // lib.rs:156-160
+            plain_compress(plan->init_state, padded.data() + r * one_round_size);
+        plan->blocks.assign(padded.begin() + (ptrdiff_t)precomputed_input_len, padded.end());   // lib.rs:170
+    }
     plan->num_round = num_round;
     plan->precomputed_round = precomputed_round;
     plan->target_round = num_round - precomputed_round;
@@ -531,7 +542,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         AssignedHashResult &r = results[i];
         const DigestPlan &pl = plans[i];
         r.input_len = input_lens[i];
-        r.input_bytes = pl.blocks;
+        r.input_bytes = std::move(plans[i].blocks);          // the plan is done with them (copied to the staging above)
         r.first_block = b0 + off;
         r.n_blocks = pl.max_variable_round;
         r.spread_cursor0 = ctx.num_limb_sum + (uint64_t)off * ctx.shape.limb_calls_per_block;
