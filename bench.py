@@ -367,7 +367,21 @@ def main():
                 rw = cfgw.digest(m56)
             dtw = (time.perf_counter() - t1) / 50
             assert rw.output_bytes == hashlib.sha256(m56).digest()
+            # ... and on to the host, where a CPU prover (create_proof) would read the advice columns
+            hostimg = cfgw.download_region(pinned=True)
+            dst = hsw._native.RegionHost(hostimg["gate"].ctypes.data, hostimg["lookup"].ctypes.data, None, None)
+            import ctypes as C
+            tdl = []
+            for _ in range(7):
+                cfgw.reset()
+                t1 = time.perf_counter()
+                rw = cfgw.digest(m56)
+                assert eng_i.lib.hsw_gadget_download_region(cfgw.h, C.byref(dst)) == 0
+                tdl.append(time.perf_counter() - t1)
             vw = cfgw.view()
+            extra["config0_bench_circuit_whole_region_to_host"] = {
+                "ms_per_synthesis": float(np.median(tdl)) * 1e3, "bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
+                "note": "synthesis + D2H of the used rows of the 9 gate columns and the lookup column into pinned memory (PCIe-bound); the chip columns would add 2 x 2 x 32,960 cells"}
             extra["config0_bench_circuit_whole_region"] = {
                 "ms_per_synthesis": dtw * 1e3, "blocks_per_s": 16 / dtw, "advice_columns": ncol,
                 "gate_cells": int(vw.gate_cells), "lookup_cells": int(vw.lookup_cells),

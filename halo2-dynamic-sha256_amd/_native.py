@@ -92,6 +92,10 @@ class HashResult(C.Structure):
         "prologue_lookup", "block_lookup", "epilogue_lookup")]
 
 
+class RegionHost(C.Structure):
+    _fields_ = [("gate", C.c_void_p), ("lookup", C.c_void_p), ("chip_dense", C.c_void_p), ("chip_spread", C.c_void_p)]
+
+
 class GadgetView(C.Structure):
     _fields_ = [("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p), ("d_chip_spread", C.c_void_p),
                 ("d_next_states", C.c_void_p), ("chip_col_stride", C.c_size_t), ("blocks_done", C.c_size_t),
@@ -113,7 +117,7 @@ SYMBOLS = (
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
-    "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek",
+    "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
 )
 
 
@@ -227,6 +231,8 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_gadget_download_region.restype = C.c_int
+        L.hsw_gadget_download_region.argtypes = [vp, C.POINTER(RegionHost)]
         L.hsw_gadget_seek.restype = C.c_int
         L.hsw_gadget_seek.argtypes = [vp, C.c_size_t]
         L.hsw_gadget_reset.restype = C.c_int

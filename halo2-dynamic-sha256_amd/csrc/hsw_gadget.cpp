@@ -122,6 +122,8 @@ struct DeviceScope {
 
 }  // namespace
 
+struct DeviceScopeG : DeviceScope { using DeviceScope::DeviceScope; };   // for the C ABI functions below
+
 int digest_prepare(const uint8_t *input, size_t input_byte_size, size_t precomputed_input_len,
                    size_t max_variable_byte_size, DigestPlan *plan) {
     if (!plan || (!input && input_byte_size)) return HSW_ERR_INVALID_ARG;
@@ -712,6 +714,46 @@ int hsw_gadget_reset(hsw_gadget *g) {
     g->cfg.cur_hash_idx = 0;            // lib.rs:66
     g->results.clear();
     return HSW_OK;
+}
+
+int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) {
+    if (!g || !dst) return HSW_ERR_INVALID_ARG;
+    hsw::Context &c = *g->ctx;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    hsw_engine_stream(c.engine, reinterpret_cast<void **>(&stream), &device);
+    hsw::DeviceScopeG ds(device);
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
+    const size_t cb = hsw_cell_bytes(c.repr_flags);
+    hipError_t he = hipSuccess;
+    auto copy = [&](void *h, const void *d, size_t cell0, size_t cells) {
+        if (he == hipSuccess && cells)
+            he = hipMemcpyAsync(static_cast<uint8_t *>(h) + cell0 * cb, static_cast<const uint8_t *>(d) + cell0 * cb,
+                                cells * cb, hipMemcpyDeviceToHost, stream);
+    };
+    if (dst->gate) {
+        if (c.whole && c.max_rows) {
+            // used rows of column k: up to its break (max_rows - gap), the last column up to the cursor
+            uint64_t last_col = 0, last_row = 0;
+            if (c.gate_cursor) { c.position(c.gate_cursor - 1, &last_col, &last_row); last_row += 1; }
+            for (uint64_t k = 0; k <= last_col && c.gate_cursor; k++) {
+                const uint64_t used = k < last_col ? c.max_rows - c.break_gap[k] : last_row;
+                copy(dst->gate, c.d_gate, (size_t)(k * c.max_rows), (size_t)used);
+            }
+        } else {
+            const size_t cells = c.whole ? (size_t)c.gate_cursor : c.blocks_done * (size_t)c.shape.gate_cells_per_block;
+            copy(dst->gate, c.d_gate, 0, cells);
+        }
+    }
+    if (dst->lookup && c.d_lookup) copy(dst->lookup, c.d_lookup, 0, (size_t)c.lookup_cursor);
+    const uint32_t ncols = c.shape.num_advice_columns;
+    const size_t rows = (size_t)((c.num_limb_sum + ncols - 1) / ncols);
+    for (uint32_t k = 0; k < ncols; k++) {
+        if (dst->chip_dense) copy(dst->chip_dense, c.d_chip_dense, k * c.chip_col_stride, rows);
+        if (dst->chip_spread) copy(dst->chip_spread, c.d_chip_spread, k * c.chip_col_stride, rows);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    return he == hipSuccess ? HSW_OK : HSW_ERR_HIP;
 }
 
 int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) {

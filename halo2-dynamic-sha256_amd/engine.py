@@ -170,6 +170,18 @@ class WitnessEngine:
         out["_keep"] = keep
         return out
 
+    def host_empty(self, shape):
+        """numpy uint64 array in page-locked memory (hsw_host_alloc); the allocation lives as long as
+        the array (it is kept alive through the array's base object)."""
+        import numpy as np
+        nbytes = int(np.prod(shape)) * 8
+        p = C.c_void_p()
+        self._ok(self.lib.hsw_host_alloc(max(nbytes, 8), C.byref(p)))
+        owner = _Pinned(self.lib, p)
+        buf = (C.c_uint8 * max(nbytes, 8)).from_address(p.value)
+        buf._owner = owner                      # numpy keeps `buf` as the array's base
+        return np.frombuffer(buf, dtype=np.uint64)[: nbytes // 8].reshape(shape)
+
     def sha256_chain(self, blocks, n_messages, blocks_per_message, init_states=None):
         """Plain SHA-256 chain pre-pass: pre-state of every block (lib.rs:188,236)."""
         t = self.torch

@@ -115,6 +115,36 @@ class Sha256DynamicConfig:
         self._ok(self.lib.hsw_gadget_reset(self.h))
         self._n = 0
 
+    def download_region(self, pinned=True):
+        """hsw_gadget_download_region into (pinned) host arrays: dict of numpy uint64 arrays shaped like
+        streams() -- gate (columns, max_rows, 4) or (cells, 4); lookup; dense / spread (ncols, stride, 4)."""
+        import numpy as np
+        v = self.view()
+        ncols = self.engine.ncols
+        img = self.whole_digest and int(v.max_rows)
+        n_gate = int(v.max_rows) * int(v.columns) if img else (
+            int(v.gate_cells) if self.whole_digest else int(v.blocks_done) * self.engine.G)
+        stride = int(v.chip_col_stride)
+
+        def buf(cells):
+            if pinned:
+                return self.engine.host_empty((max(cells, 1), 4))
+            return np.zeros((max(cells, 1), 4), dtype=np.uint64)
+        gate, dense, spread = buf(n_gate), buf(ncols * stride), buf(ncols * stride)
+        lookup = buf(int(v.lookup_cells)) if self.whole_digest else None
+        if img:
+            gate[:] = 0                                    # unassigned tail rows of a column stay zero
+        dst = N.RegionHost(gate.ctypes.data, lookup.ctypes.data if lookup is not None else None,
+                           dense.ctypes.data, spread.ctypes.data)
+        self._ok(self.lib.hsw_gadget_download_region(self.h, C.byref(dst)))
+        rows = (int(v.num_limb_sum) + ncols - 1) // ncols
+        out = dict(gate=gate[:n_gate].reshape(int(v.columns), int(v.max_rows), 4) if img else gate[:n_gate],
+                   dense=dense.reshape(ncols, stride, 4)[:, :rows], spread=spread.reshape(ncols, stride, 4)[:, :rows],
+                   rows=rows)
+        if lookup is not None:
+            out["lookup"] = lookup[: int(v.lookup_cells)]
+        return out
+
     def seek(self, hash_idx):
         """Continue at digest #hash_idx as if the earlier ones had been assigned (their positions
         follow from max_variable_byte_sizes alone): lets several GPUs share one circuit's digests."""

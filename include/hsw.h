@@ -395,6 +395,17 @@ int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns
  * cell).  What the reference's harnesses do by cloning the config per synthesis
  * (lib.rs:440, benches/digest.rs:78).  Waits for outstanding work on the engine. */
 int hsw_gadget_reset(hsw_gadget *g);
+/* Host delivery of what the gadget has written so far (a CPU prover reads advice columns from host
+ * memory).  Every pointer may be NULL (skipped).  Layouts equal the device ones: `gate` is the column
+ * image (columns x max_rows cells; only the used rows of each column are copied) or, without
+ * hsw_gadget_set_columns, the linear stream; `lookup` the lookup-advice stream (whole-digest contexts);
+ * `chip_dense` / `chip_spread` ncols columns chip_col_stride cells apart (used rows copied).  One pass
+ * of asynchronous copies on the engine's stream, then a synchronize; fastest into pinned memory
+ * (hsw_host_alloc).  PCIe-bound: the bench circuit's region is 37 MB. */
+typedef struct hsw_region_host {
+    void *gate, *lookup, *chip_dense, *chip_spread;
+} hsw_region_host;
+int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst);
 /* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
  * (cur_hash_idx, num_limb_sum, the gate / lookup stream cursors, the zero cell) takes the value it
  * would have then.  All of them follow from max_variable_byte_sizes alone -- never from the

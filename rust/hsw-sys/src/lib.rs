@@ -150,6 +150,15 @@ pub struct hsw_hash_result {
     pub epilogue_lookup: u64,
 }
 
+/// Host destinations of `hsw_gadget_download_region` (any may be null).
+#[repr(C)]
+pub struct hsw_region_host {
+    pub gate: *mut c_void,
+    pub lookup: *mut c_void,
+    pub chip_dense: *mut c_void,
+    pub chip_spread: *mut c_void,
+}
+
 #[repr(C)]
 pub struct hsw_gadget_view {
     pub d_gate: *mut c_void,
@@ -221,6 +230,7 @@ extern "C" {
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
+    pub fn hsw_gadget_download_region(g: *mut hsw_gadget, dst: *const hsw_region_host) -> c_int;
     pub fn hsw_gadget_cell_position(g: *const hsw_gadget, cell: u64, column: *mut u64, row: *mut u64) -> c_int;
     pub fn hsw_frame_query(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                            out: *mut hsw_frame_shape) -> c_int;

@@ -337,3 +337,32 @@ def test_seek_deals_one_circuit_to_two_gadgets(hsw, oracle, eng_int, columns):
     for m, r in zip(msgs[2:], b["res"]):
         assert r.output_bytes == hashlib.sha256(m).digest()
     assert [r.prologue_cell for r in b["res"]] == [r.prologue_cell for r in full["res"][2:]]
+
+
+@pytest.mark.parametrize("columns", [False, True])
+def test_download_region_to_host(hsw, oracle, eng_int, columns):
+    """hsw_gadget_download_region: the region in host memory (pinned), used rows only, equal to the
+    device image."""
+    sizes, msgs = [128, 64], [b"host delivery", b"z"]
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+    if columns:
+        cfg.set_columns(100000)
+    cfg.digest_batch(msgs, [None, None])
+    dev = cfg.streams()
+    for pinned in (True, False):
+        host = cfg.download_region(pinned=pinned)
+        assert np.array_equal(host["gate"], dev["gate"])
+        assert np.array_equal(host["lookup"], dev["lookup"])
+        assert np.array_equal(host["dense"], dev["dense"]) and np.array_equal(host["spread"], dev["spread"])
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    exp = _model_columns(ref["call_lens"], ref["gate"], 100000)[0] if columns else ref["gate"]
+    assert np.array_equal(host["gate"], exp)
+    cfg.close()
+    # block-stream contexts deliver too
+    eng = hsw.WitnessEngine(0, 8, 2)
+    plain = hsw.Sha256DynamicConfig(eng, [128], True)
+    plain.digest(b"abc")
+    d, h = plain.streams(), plain.download_region()
+    assert np.array_equal(h["gate"], d["gate"]) and np.array_equal(h["dense"], d["dense"]) and "lookup" not in h
+    plain.close()
+    eng.close()
