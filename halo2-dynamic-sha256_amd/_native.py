@@ -92,6 +92,14 @@ class HashResult(C.Structure):
         "prologue_lookup", "block_lookup", "epilogue_lookup")]
 
 
+class StructureCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("gate_cells", "gate_rows", "assert_eq", "ranges", "lookups", "limb_calls")]
+
+
+class FrameStructureCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("cells", "gate_rows", "assert_eq", "assert_const", "ranges", "lookups")]
+
+
 class RegionHost(C.Structure):
     _fields_ = [("gate", C.c_void_p), ("lookup", C.c_void_p), ("chip_dense", C.c_void_p), ("chip_spread", C.c_void_p)]
 
@@ -118,6 +126,7 @@ SYMBOLS = (
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
+    "hsw_block_structure", "hsw_frame_structure",
 )
 
 
@@ -231,6 +240,11 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_frame_structure.restype = C.c_int
+        L.hsw_frame_structure.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_int, C.c_int,
+                                          C.POINTER(FrameStructureCounts)] + [vp] * 7
+        L.hsw_block_structure.restype = C.c_int
+        L.hsw_block_structure.argtypes = [C.POINTER(Shape), C.POINTER(StructureCounts)] + [vp] * 8
         L.hsw_gadget_download_region.restype = C.c_int
         L.hsw_gadget_download_region.argtypes = [vp, C.POINTER(RegionHost)]
         L.hsw_gadget_seek.restype = C.c_int
@@ -343,3 +357,48 @@ def frame_tape(shape, max_variable_byte_size, is_input_range_check, section):
     if rc != HSW_OK:
         raise HswError(rc)
     return lens
+
+
+def block_structure(shape):
+    """hsw_block_structure as a dict of numpy arrays: kind (G,) u8, ref (G,) i64, gate_rows (n,) u32,
+    assert_eq (n,2), range (n,2), lookup_src (LK,), chip (LC,2), next_state (8,) -- all i64 cell ids."""
+    import numpy as np
+    c = StructureCounts()
+    rc = lib().hsw_block_structure(C.byref(shape), C.byref(c), None, None, None, None, None, None, None, None)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    kind = np.zeros(c.gate_cells, dtype=np.uint8)
+    ref = np.zeros(c.gate_cells, dtype=np.int64)
+    rows = np.zeros(c.gate_rows, dtype=np.uint32)
+    aeq = np.zeros((c.assert_eq, 2), dtype=np.int64)
+    rng = np.zeros((c.ranges, 2), dtype=np.int64)
+    lk = np.zeros(c.lookups, dtype=np.int64)
+    chip = np.zeros((c.limb_calls, 2), dtype=np.int64)
+    ns = np.zeros(8, dtype=np.int64)
+    rc = lib().hsw_block_structure(C.byref(shape), None, kind.ctypes.data, ref.ctypes.data, rows.ctypes.data,
+                                   aeq.ctypes.data, rng.ctypes.data, lk.ctypes.data, chip.ctypes.data, ns.ctypes.data)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return dict(kind=kind, ref=ref, gate_rows=rows, assert_eq=aeq, range=rng, lookup_src=lk, chip=chip, next_state=ns)
+
+
+def frame_structure(shape, max_variable_byte_size, is_input_range_check, section):
+    """hsw_frame_structure as a dict of numpy arrays (section 0 = prologue, 1 = epilogue)."""
+    import numpy as np
+    c = FrameStructureCounts()
+    args = (C.byref(shape), max_variable_byte_size, 1 if is_input_range_check else 0, section)
+    rc = lib().hsw_frame_structure(*args, C.byref(c), None, None, None, None, None, None, None)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    kind = np.zeros(c.cells, dtype=np.uint8)
+    ref = np.zeros(c.cells, dtype=np.int64)
+    rows = np.zeros(c.gate_rows, dtype=np.uint32)
+    aeq = np.zeros((c.assert_eq, 2), dtype=np.int64)
+    ac = np.zeros((c.assert_const, 2), dtype=np.int64)
+    rng = np.zeros((c.ranges, 2), dtype=np.int64)
+    lk = np.zeros(c.lookups, dtype=np.int64)
+    rc = lib().hsw_frame_structure(*args, None, kind.ctypes.data, ref.ctypes.data, rows.ctypes.data, aeq.ctypes.data,
+                                   ac.ctypes.data, rng.ctypes.data, lk.ctypes.data)
+    if rc != HSW_OK:
+        raise HswError(rc)
+    return dict(kind=kind, ref=ref, gate_rows=rows, assert_eq=aeq, assert_const=ac, range=rng, lookup_src=lk)

@@ -17,6 +17,7 @@
 #include "hsw_frame.hpp"
 #include "hsw_kernels.h"
 #include "hsw_layout.h"
+#include "hsw_structure.hpp"
 #include "hsw_tape.hpp"
 
 struct hsw_engine {
@@ -487,6 +488,34 @@ int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t 
     return HSW_OK;
 }
 
+int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, uint8_t *cell_kind,
+                        int64_t *cell_ref, uint32_t *gate_rows, int64_t *assert_eq, int64_t *range,
+                        int64_t *lookup_src, int64_t *chip, int64_t *next_state) {
+    if (!shape || shape->limbs_per_spread == 0 || 16 % shape->limbs_per_spread != 0) return HSW_ERR_INVALID_ARG;
+    const hsw::BlockStructure st =
+        hsw::StructureBuilder((int)shape->limbs_per_spread, shape->mode == HSW_MODE_HALO2_INTERNALS).block();
+    if (st.kind.size() != shape->gate_cells_per_block || st.chip.size() != 2u * shape->limb_calls_per_block ||
+        st.lookup_src.size() != shape->lookup_cells_per_block)
+        return HSW_ERR_INVALID_ARG;                      // the builder and the layout arithmetic must agree
+    if (counts) {
+        counts->gate_cells = st.kind.size();
+        counts->gate_rows = st.gate_rows.size();
+        counts->assert_eq = st.assert_eq.size() / 2;
+        counts->ranges = st.range.size() / 2;
+        counts->lookups = st.lookup_src.size();
+        counts->limb_calls = st.chip.size() / 2;
+    }
+    if (cell_kind) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
+    if (cell_ref) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
+    if (gate_rows) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
+    if (assert_eq) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
+    if (range) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
+    if (lookup_src) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
+    if (chip) std::memcpy(chip, st.chip.data(), st.chip.size() * sizeof(int64_t));
+    if (next_state) std::memcpy(next_state, st.next_state, sizeof st.next_state);
+    return HSW_OK;
+}
+
 // ------------------------------------------------------------ digest frames
 int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
                     hsw_frame_shape *out) {
@@ -535,6 +564,38 @@ int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is
         if (cap < lens.size()) return HSW_ERR_INVALID_ARG;
         std::memcpy(lens_out, lens.data(), lens.size());
     }
+    return HSW_OK;
+}
+
+int hsw_frame_structure(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                        int section, hsw_frame_structure_counts *counts, uint8_t *cell_kind, int64_t *cell_ref,
+                        uint32_t *gate_rows, int64_t *assert_eq, int64_t *assert_const, int64_t *range,
+                        int64_t *lookup_src) {
+    hsw_frame_shape fs;
+    const int rc = hsw_frame_query(shape, max_variable_byte_size, is_input_range_check, &fs);
+    if (rc != HSW_OK) return rc;
+    if (section != 0 && section != 1) return HSW_ERR_INVALID_ARG;
+    hsw::FrameStructureBuilder b;
+    const hsw::FrameStructure st = section == 0 ? b.prologue(max_variable_byte_size, is_input_range_check != 0)
+                                                : b.epilogue(fs.n_blocks);
+    if (st.kind.size() != (section ? fs.epilogue_cells : fs.prologue_cells) ||
+        st.lookup_src.size() != (section ? fs.epilogue_lookups : fs.prologue_lookups))
+        return HSW_ERR_INVALID_ARG;                      // the builder and the layout arithmetic must agree
+    if (counts) {
+        counts->cells = st.kind.size();
+        counts->gate_rows = st.gate_rows.size();
+        counts->assert_eq = st.assert_eq.size() / 2;
+        counts->assert_const = st.assert_const.size() / 2;
+        counts->ranges = st.range.size() / 2;
+        counts->lookups = st.lookup_src.size();
+    }
+    if (cell_kind) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
+    if (cell_ref) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
+    if (gate_rows) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
+    if (assert_eq) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
+    if (assert_const) std::memcpy(assert_const, st.assert_const.data(), st.assert_const.size() * sizeof(int64_t));
+    if (range) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
+    if (lookup_src) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
     return HSW_OK;
 }
 

@@ -203,6 +203,33 @@ int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_
  * NULL to query the count. */
 int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls);
 
+/* The constraint STRUCTURE of one block's gate stream (input independent): for every cell which
+ * QuantumCell the reference hands to halo2-base there, plus everything else a replayer needs to
+ * rebuild the gadget's constraint system around the value streams (what halo2 key generation
+ * records): gate rows, assert_equal pairs, range_check bounds, lookup sources, spread-chip ties.
+ * Built on the host by walking the reference's call sequence on symbolic cells
+ * (csrc/hsw_structure.hpp); follows the engine mode of `shape` (HSW_MODE_HALO2_INTERNALS adds the
+ * range_check rows).  Cell ids: >= 0 = block-relative stream index; < 0 = outside the block:
+ * HSW_CELL_INPUT_BYTE0 - k (input byte k), HSW_CELL_PRE_STATE0 - i (pre-state word i),
+ * HSW_CELL_ZERO (the Context's zero cell), HSW_CELL_HIDDEN (a halo2-base witness not in the stream). */
+#define HSW_CELL_INPUT_BYTE0 (-1)
+#define HSW_CELL_PRE_STATE0  (-100)
+#define HSW_CELL_ZERO        (-1000)
+#define HSW_CELL_HIDDEN      (-2000)
+#define HSW_KIND_WITNESS  0
+#define HSW_KIND_CONSTANT 1   /* cell_ref = the constant */
+#define HSW_KIND_EXISTING 2   /* cell_ref = the cell it is copy-constrained to */
+typedef struct hsw_structure_counts {
+    uint64_t gate_cells, gate_rows, assert_eq, ranges, lookups, limb_calls;
+} hsw_structure_counts;
+/* Any output pointer may be NULL.  Sizes: cell_kind / cell_ref gate_cells; gate_rows gate_rows (first
+ * cell of each row x0 + x1*x2 = x3); assert_eq 2*assert_eq; range 2*ranges (cell, bits); lookup_src
+ * lookups; chip 2*limb_calls (cell tied to the dense chip cell, cell tied to the spread chip cell);
+ * next_state 8 (the cells holding the block's output words). */
+int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, uint8_t *cell_kind,
+                        int64_t *cell_ref, uint32_t *gate_rows, int64_t *assert_eq, int64_t *range,
+                        int64_t *lookup_src, int64_t *chip, int64_t *next_state);
+
 typedef struct hsw_witness_args {
     const uint8_t *d_blocks;       /* as hsw_witness_blocks */
     const uint32_t *d_pre_states;
@@ -314,6 +341,21 @@ int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int i
  * (section 1), like hsw_gate_tape.  lens_out may be NULL to query the count. */
 int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
                    int section, uint8_t *lens_out, size_t cap, size_t *n_calls);
+
+/* Constraint structure of the prologue (section 0) / epilogue (section 1), like hsw_block_structure.
+ * Cell ids are section-relative; negative ids name cells of other sections: HSW_CELL_ZERO,
+ * HSW_CELL_TARGET (assigned_target_round: prologue cell 34), HSW_CELL_STATE0 - (8 n + i) (word i of
+ * candidate state n: n = 0 the prologue's cells 38..45, n >= 1 the next_state cells of block n - 1).
+ * assert_const: pairs (cell, k) from assert_is_const.  Constants: -k stands for p - k. */
+#define HSW_CELL_TARGET (-3000)
+#define HSW_CELL_STATE0 (-4000)
+typedef struct hsw_frame_structure_counts {
+    uint64_t cells, gate_rows, assert_eq, assert_const, ranges, lookups;
+} hsw_frame_structure_counts;
+int hsw_frame_structure(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
+                        int section, hsw_frame_structure_counts *counts, uint8_t *cell_kind, int64_t *cell_ref,
+                        uint32_t *gate_rows, int64_t *assert_eq, int64_t *assert_const, int64_t *range,
+                        int64_t *lookup_src);
 
 typedef struct hsw_frame_desc {   /* one digest() call */
     uint64_t input_len;           /* lib.rs:77 */

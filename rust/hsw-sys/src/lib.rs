@@ -150,6 +150,41 @@ pub struct hsw_hash_result {
     pub epilogue_lookup: u64,
 }
 
+pub const HSW_CELL_INPUT_BYTE0: i64 = -1;
+pub const HSW_CELL_PRE_STATE0: i64 = -100;
+pub const HSW_CELL_ZERO: i64 = -1000;
+pub const HSW_CELL_HIDDEN: i64 = -2000;
+pub const HSW_KIND_WITNESS: u8 = 0;
+pub const HSW_KIND_CONSTANT: u8 = 1;
+pub const HSW_KIND_EXISTING: u8 = 2;
+
+pub const HSW_CELL_TARGET: i64 = -3000;
+pub const HSW_CELL_STATE0: i64 = -4000;
+
+/// Sizes of the arrays `hsw_frame_structure` fills.
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_frame_structure_counts {
+    pub cells: u64,
+    pub gate_rows: u64,
+    pub assert_eq: u64,
+    pub assert_const: u64,
+    pub ranges: u64,
+    pub lookups: u64,
+}
+
+/// Sizes of the arrays `hsw_block_structure` fills.
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_structure_counts {
+    pub gate_cells: u64,
+    pub gate_rows: u64,
+    pub assert_eq: u64,
+    pub ranges: u64,
+    pub lookups: u64,
+    pub limb_calls: u64,
+}
+
 /// Host destinations of `hsw_gadget_download_region` (any may be null).
 #[repr(C)]
 pub struct hsw_region_host {
@@ -230,6 +265,13 @@ extern "C" {
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
+    pub fn hsw_frame_structure(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
+                               section: c_int, counts: *mut hsw_frame_structure_counts, cell_kind: *mut u8,
+                               cell_ref: *mut i64, gate_rows: *mut u32, assert_eq: *mut i64,
+                               assert_const: *mut i64, range: *mut i64, lookup_src: *mut i64) -> c_int;
+    pub fn hsw_block_structure(shape: *const hsw_shape, counts: *mut hsw_structure_counts, cell_kind: *mut u8,
+                               cell_ref: *mut i64, gate_rows: *mut u32, assert_eq: *mut i64, range: *mut i64,
+                               lookup_src: *mut i64, chip: *mut i64, next_state: *mut i64) -> c_int;
     pub fn hsw_gadget_download_region(g: *mut hsw_gadget, dst: *const hsw_region_host) -> c_int;
     pub fn hsw_gadget_cell_position(g: *const hsw_gadget, cell: u64, column: *mut u64, row: *mut u64) -> c_int;
     pub fn hsw_frame_query(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,

@@ -64,6 +64,37 @@ int main() {
             }
         }
     }
+    {   // constraint structure builders with exact-size buffers
+        for (uint32_t mode : {HSW_MODE_DEFAULT, HSW_MODE_HALO2_INTERNALS}) {
+            hsw_shape s;
+            CHECK(hsw_shape_query_ex(8, 2, mode, &s) == HSW_OK);
+            hsw_structure_counts c;
+            CHECK(hsw_block_structure(&s, &c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == HSW_OK);
+            CHECK(c.gate_cells == s.gate_cells_per_block && c.limb_calls == s.limb_calls_per_block && c.assert_eq >= 3850);
+            std::vector<uint8_t> kind(c.gate_cells);
+            std::vector<int64_t> ref(c.gate_cells), aeq(2 * c.assert_eq), rng(2 * c.ranges), lk(c.lookups), chip(2 * c.limb_calls);
+            std::vector<uint32_t> rows(c.gate_rows);
+            int64_t ns[8];
+            CHECK(hsw_block_structure(&s, nullptr, kind.data(), ref.data(), rows.data(), aeq.data(), rng.data(), lk.data(),
+                                      chip.data(), ns) == HSW_OK);
+            for (size_t i = 0; i < kind.size(); i++)
+                CHECK(kind[i] <= HSW_KIND_EXISTING && (kind[i] != HSW_KIND_EXISTING || ref[i] < (int64_t)i));   // copies point backwards
+            for (uint32_t r : rows) CHECK(r + 3 < c.gate_cells);
+        }
+        hsw_shape si;
+        CHECK(hsw_shape_query_ex(8, 2, HSW_MODE_HALO2_INTERNALS, &si) == HSW_OK);
+        for (int section = 0; section < 2; section++) {
+            hsw_frame_structure_counts fc;
+            CHECK(hsw_frame_structure(&si, 192, 1, section, &fc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == HSW_OK);
+            std::vector<uint8_t> kind(fc.cells);
+            std::vector<int64_t> ref(fc.cells), aeq(2 * fc.assert_eq), ac(2 * fc.assert_const + 2), rng(2 * fc.ranges), lk(fc.lookups);
+            std::vector<uint32_t> rows(fc.gate_rows);
+            CHECK(hsw_frame_structure(&si, 192, 1, section, nullptr, kind.data(), ref.data(), rows.data(), aeq.data(), ac.data(),
+                                      rng.data(), lk.data()) == HSW_OK);
+            for (uint32_t r : rows) CHECK(r + 3 < fc.cells);
+        }
+        CHECK(hsw_frame_structure(&si, 192, 1, 2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == HSW_ERR_INVALID_ARG);
+    }
     hsw_shape bad;
     CHECK(hsw_shape_query(3, 2, &bad) == HSW_ERR_SHAPE);
     CHECK(hsw_shape_query(8, 0, &bad) == HSW_ERR_SHAPE);
