@@ -505,13 +505,13 @@ int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, ui
         counts->lookups = st.lookup_src.size();
         counts->limb_calls = st.chip.size() / 2;
     }
-    if (cell_kind) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
-    if (cell_ref) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
-    if (gate_rows) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
-    if (assert_eq) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
-    if (range) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
-    if (lookup_src) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
-    if (chip) std::memcpy(chip, st.chip.data(), st.chip.size() * sizeof(int64_t));
+    if (cell_kind && !st.kind.empty()) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
+    if (cell_ref && !st.ref.empty()) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
+    if (gate_rows && !st.gate_rows.empty()) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
+    if (assert_eq && !st.assert_eq.empty()) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
+    if (range && !st.range.empty()) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
+    if (lookup_src && !st.lookup_src.empty()) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
+    if (chip && !st.chip.empty()) std::memcpy(chip, st.chip.data(), st.chip.size() * sizeof(int64_t));
     if (next_state) std::memcpy(next_state, st.next_state, sizeof st.next_state);
     return HSW_OK;
 }
@@ -589,13 +589,13 @@ int hsw_frame_structure(const hsw_shape *shape, size_t max_variable_byte_size, i
         counts->ranges = st.range.size() / 2;
         counts->lookups = st.lookup_src.size();
     }
-    if (cell_kind) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
-    if (cell_ref) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
-    if (gate_rows) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
-    if (assert_eq) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
-    if (assert_const) std::memcpy(assert_const, st.assert_const.data(), st.assert_const.size() * sizeof(int64_t));
-    if (range) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
-    if (lookup_src) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
+    if (cell_kind && !st.kind.empty()) std::memcpy(cell_kind, st.kind.data(), st.kind.size());
+    if (cell_ref && !st.ref.empty()) std::memcpy(cell_ref, st.ref.data(), st.ref.size() * sizeof(int64_t));
+    if (gate_rows && !st.gate_rows.empty()) std::memcpy(gate_rows, st.gate_rows.data(), st.gate_rows.size() * sizeof(uint32_t));
+    if (assert_eq && !st.assert_eq.empty()) std::memcpy(assert_eq, st.assert_eq.data(), st.assert_eq.size() * sizeof(int64_t));
+    if (assert_const && !st.assert_const.empty()) std::memcpy(assert_const, st.assert_const.data(), st.assert_const.size() * sizeof(int64_t));
+    if (range && !st.range.empty()) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
+    if (lookup_src && !st.lookup_src.empty()) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
     return HSW_OK;
 }
 
