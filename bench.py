@@ -287,6 +287,17 @@ def main():
         except Exception as ex:
             extra["compact64_repr"] = {"error": repr(ex)}
     if not args.no_extra and rank == 0:
+        # the product's own MockProver-style check of the batch just written, in HBM (hsw_verify_blocks)
+        try:
+            reps_v = [eng.verify_blocks(blocks, pre, out, cursor0=cursor0) for _ in range(3)]
+            vms = float(np.median([r["kernel_ms"] for r in reps_v]))
+            extra["verify_on_device"] = {"violations": reps_v[-1]["violations"], "checks": reps_v[-1]["checks"],
+                                         "kernel_ms": vms, "blocks_per_s": n / vms * 1e3,
+                                         "read_GBps": alg_bytes * n / vms / 1e6,
+                                         "note": "every gate row, copy constraint, constant, range bound, chip cell / spread-table row and next state of all blocks"}
+        except Exception as ex:
+            extra["verify_on_device"] = {"error": repr(ex)}
+    if not args.no_extra and rank == 0:
         # configs[1]: one 1 KiB-class message = 16 chained blocks (1,015 bytes)
         m = bytes(((i * 131 + 7) % 256) for i in range(1015))
         padded = bytearray(m) + b"\x80" + b"\x00" * ((64 - (len(m) + 9) % 64) % 64) + (8 * len(m)).to_bytes(8, "big")

@@ -96,6 +96,13 @@ class StructureCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("gate_cells", "gate_rows", "assert_eq", "ranges", "lookups", "limb_calls")]
 
 
+class VerifyReport(C.Structure):
+    _fields_ = [("violations", C.c_uint64), ("checks", C.c_uint64), ("first_block", C.c_uint64),
+                ("first_cell", C.c_int64), ("first_class", C.c_uint32), ("kernel_ms", C.c_float)]
+    CLASSES = {1: "constant", 2: "copy", 3: "gate row", 4: "assert_equal", 5: "range", 6: "chip", 7: "lookup",
+               8: "next state"}
+
+
 class FrameStructureCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("cells", "gate_rows", "assert_eq", "assert_const", "ranges", "lookups")]
 
@@ -126,7 +133,7 @@ SYMBOLS = (
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
-    "hsw_block_structure", "hsw_frame_structure",
+    "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
 )
 
 
@@ -240,6 +247,8 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_verify_blocks.restype = C.c_int
+        L.hsw_verify_blocks.argtypes = [vp, C.POINTER(WitnessArgs), C.POINTER(VerifyReport)]
         L.hsw_frame_structure.restype = C.c_int
         L.hsw_frame_structure.argtypes = [C.POINTER(Shape), C.c_size_t, C.c_int, C.c_int,
                                           C.POINTER(FrameStructureCounts)] + [vp] * 7

@@ -19,6 +19,7 @@
 #include "hsw_layout.h"
 #include "hsw_structure.hpp"
 #include "hsw_tape.hpp"
+#include "hsw_verify.h"
 
 struct hsw_engine {
     int device = 0;
@@ -54,6 +55,11 @@ struct hsw_engine {
     unsigned frame_next = 0;
     uint64_t *d_inv_tbl[2] = {nullptr, nullptr};
     size_t inv_n = 0;
+    // on-device verification (hsw_verify_blocks): the block structure, uploaded on first use
+    void *d_structure = nullptr;
+    hsw::VerifyParams verify_tpl{};      // structure pointers / counts filled in
+    uint64_t verify_checks_per_block = 0;
+    hsw::VerifyReport *d_report = nullptr;
 };
 
 namespace {
@@ -273,6 +279,8 @@ void hsw_engine_destroy(hsw_engine *e) {
             if (fs.h) (void)hipHostFree(fs.h);
             if (fs.done) (void)hipEventDestroy(fs.done);
         }
+        if (e->d_structure) (void)hipFree(e->d_structure);
+        if (e->d_report) (void)hipFree(e->d_report);
         if (e->d_inv_tbl[0]) (void)hipFree(e->d_inv_tbl[0]);
         if (e->d_inv_tbl[1]) (void)hipFree(e->d_inv_tbl[1]);
         if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -563,6 +571,92 @@ int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is
     if (lens_out) {
         if (cap < lens.size()) return HSW_ERR_INVALID_ARG;
         std::memcpy(lens_out, lens.data(), lens.size());
+    }
+    return HSW_OK;
+}
+
+// ------------------------------------------------------------ on-device verification
+static int ensure_structure(hsw_engine *e) {
+    if (e->d_structure) return HSW_OK;
+    const hsw::BlockStructure st = hsw::StructureBuilder(e->limbs, e->mode == HSW_MODE_HALO2_INTERNALS).block();
+    // one device allocation: [ref | assert_eq | range | chip | lookup_src | next_state | gate_rows | kind]
+    const size_t n_i64 = st.ref.size() + st.assert_eq.size() + st.range.size() + st.chip.size() + st.lookup_src.size() + 8;
+    const size_t bytes = n_i64 * 8 + st.gate_rows.size() * 4 + st.kind.size();
+    std::vector<uint8_t> h(bytes);
+    size_t at = 0;
+    auto put = [&](const void *src, size_t n) { if (n) std::memcpy(h.data() + at, src, n); const size_t was = at; at += n; return was; };
+    const size_t o_ref = put(st.ref.data(), st.ref.size() * 8), o_aeq = put(st.assert_eq.data(), st.assert_eq.size() * 8);
+    const size_t o_rng = put(st.range.data(), st.range.size() * 8), o_chip = put(st.chip.data(), st.chip.size() * 8);
+    const size_t o_lk = put(st.lookup_src.data(), st.lookup_src.size() * 8), o_ns = put(st.next_state, 64);
+    const size_t o_rows = put(st.gate_rows.data(), st.gate_rows.size() * 4), o_kind = put(st.kind.data(), st.kind.size());
+    void *d = nullptr;
+    hipError_t he = hipMalloc(&d, bytes);
+    if (he == hipSuccess) he = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc((void **)&e->d_report, sizeof(hsw::VerifyReport));
+    if (he != hipSuccess) { if (d) (void)hipFree(d); return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "structure upload", he); }
+    e->d_structure = d;
+    const uint8_t *b = static_cast<const uint8_t *>(d);
+    hsw::VerifyParams &p = e->verify_tpl;
+    p.ref = reinterpret_cast<const int64_t *>(b + o_ref);
+    p.assert_eq = reinterpret_cast<const int64_t *>(b + o_aeq);
+    p.range = reinterpret_cast<const int64_t *>(b + o_rng);
+    p.chip = reinterpret_cast<const int64_t *>(b + o_chip);
+    p.lookup_src = reinterpret_cast<const int64_t *>(b + o_lk);
+    p.next_state_cells = reinterpret_cast<const int64_t *>(b + o_ns);
+    p.gate_rows = reinterpret_cast<const uint32_t *>(b + o_rows);
+    p.kind = b + o_kind;
+    p.gate_cells = (uint32_t)st.kind.size();
+    p.n_rows = (uint32_t)st.gate_rows.size();
+    p.n_assert_eq = (uint32_t)(st.assert_eq.size() / 2);
+    p.n_range = (uint32_t)(st.range.size() / 2);
+    p.limb_calls = (uint32_t)(st.chip.size() / 2);
+    p.lookup_cells = (uint32_t)st.lookup_src.size();
+    uint64_t fixed = 0;
+    for (uint8_t k : st.kind) fixed += k != 0;
+    e->verify_checks_per_block = fixed + p.n_rows + p.n_assert_eq + p.n_range;
+    return HSW_OK;
+}
+
+int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_report *report) {
+    if (!e || !args || !report) return HSW_ERR_INVALID_ARG;
+    std::memset(report, 0, sizeof *report);
+    if (args->n_blocks == 0) return HSW_OK;
+    if (!args->d_gate || !args->d_blocks || !args->d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    if (args->flags & HSW_REPR_MASK) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks canonical cells");
+    if (args->pack || args->frame_every) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks plain linear streams");
+    if ((args->d_chip_dense == nullptr) != (args->d_chip_spread == nullptr)) return set_err(e, HSW_ERR_INVALID_ARG, "both chip families or none");
+    if (args->d_lookup && e->mode != HSW_MODE_HALO2_INTERNALS) return set_err(e, HSW_ERR_INVALID_ARG, "d_lookup needs HSW_MODE_HALO2_INTERNALS");
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    const int rc = ensure_structure(e);
+    if (rc != HSW_OK) return rc;
+    hsw::VerifyParams p = e->verify_tpl;
+    p.gate = args->d_gate; p.chip_dense = args->d_chip_dense; p.chip_spread = args->d_chip_spread; p.lookup = args->d_lookup;
+    p.blocks = args->d_blocks; p.pre_states = args->d_pre_states; p.next_states = args->d_next_states;
+    p.cursor0 = args->spread_cursor0; p.chip_col_stride = args->chip_col_stride;
+    p.ncols = e->shape.num_advice_columns; p.num_bits_lookup = e->shape.num_bits_lookup;
+    p.report = e->d_report;
+    const hsw::VerifyReport zero{0, ~0ull, 0, 0};
+    hipError_t he = hipMemcpyAsync(e->d_report, &zero, sizeof zero, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(e->ev0, e->stream);
+    if (he == hipSuccess) he = hsw::launch_verify(p, args->n_blocks, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(e->ev1, e->stream);
+    hsw::VerifyReport got{};
+    if (he == hipSuccess) he = hipMemcpyAsync(&got, e->d_report, sizeof got, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipEventElapsedTime(&report->kernel_ms, e->ev0, e->ev1);
+    e->timed = false;
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_verify_blocks", he);
+    report->violations = got.violations;
+    uint64_t per_block = e->verify_checks_per_block;
+    if (args->d_chip_dense) per_block += 4ull * p.limb_calls;
+    if (args->d_lookup) per_block += 2ull * p.lookup_cells;
+    if (args->d_next_states) per_block += 8;
+    report->checks = per_block * args->n_blocks;
+    if (got.violations) {
+        report->first_block = got.first_key >> 32;
+        report->first_cell = (int64_t)(got.first_key & 0xffffffffu);
+        report->first_class = got.first_class;
     }
     return HSW_OK;
 }

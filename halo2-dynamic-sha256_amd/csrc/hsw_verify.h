@@ -1,0 +1,46 @@
+// hsw_verify.h -- launch interface of the on-device constraint check (hsw_verify.hip).
+#ifndef HSW_VERIFY_H
+#define HSW_VERIFY_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hsw {
+
+enum : uint32_t {      // mirrors HSW_VERIFY_* of include/hsw.h
+    VERIFY_CONSTANT = 1, VERIFY_COPY = 2, VERIFY_GATE_ROW = 3, VERIFY_ASSERT_EQ = 4, VERIFY_RANGE = 5,
+    VERIFY_CHIP = 6, VERIFY_LOOKUP = 7, VERIFY_NEXT_STATE = 8,
+};
+
+struct VerifyReport {              // device memory
+    uint64_t violations;
+    uint64_t first_key;            // (block << 32) | cell of the earliest failure; ~0 = none
+    uint32_t first_class;
+    uint32_t pad_;
+};
+
+struct VerifyParams {
+    // the witness and its inputs (as given to hsw_witness_blocks)
+    const void *gate;              // n_blocks * gate_cells canonical cells
+    const void *chip_dense, *chip_spread;   // may be null (skipped)
+    const void *lookup;            // may be null
+    const uint8_t *blocks;
+    const uint32_t *pre_states;
+    const uint32_t *next_states;   // may be null
+    uint64_t cursor0;
+    uint64_t chip_col_stride;
+    uint32_t ncols, num_bits_lookup;
+    // the structure (device copies of hsw::BlockStructure)
+    uint32_t gate_cells, n_rows, n_assert_eq, n_range, limb_calls, lookup_cells;
+    const uint8_t *kind;
+    const int64_t *ref;
+    const uint32_t *gate_rows;
+    const int64_t *assert_eq, *range, *chip, *lookup_src, *next_state_cells;
+    VerifyReport *report;
+};
+
+hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream);
+
+}  // namespace hsw
+#endif

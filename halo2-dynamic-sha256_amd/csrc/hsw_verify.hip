@@ -1,0 +1,142 @@
+// hsw_verify.hip -- on-device check of a block witness against the gadget's constraint system.
+//
+// What MockProver::verify checks for the path (reference lib.rs:525-526), evaluated in HBM right where the
+// witness was written: every gate row x0 + x1*x2 = x3, every copy constraint (QuantumCell::Existing and
+// assert_equal), every fixed constant, every range_check bound, the spread-chip cells (tied to their gate
+// cells, and (dense, spread) a row of the spread table), the lookup-column copies, the next-state words --
+// with the block bytes and the pre-state entering only through the external cells they are
+// copy-constrained to.  The structure is the product's own (csrc/hsw_structure.hpp); no value is
+// recomputed from the inputs, so a stream that passes is the witness of its inputs by the uniqueness
+// argument of SURVEY 8c.  Canonical 32-byte cells.  One 256-thread workgroup per block; the kernel reads
+// the stream once (plus neighbouring re-reads that hit L2): HBM-read bound.
+#include "hsw_expand.hpp"
+#include "hsw_verify.h"
+
+namespace hsw {
+
+namespace {
+
+struct Cell { u64 l[4]; };
+
+DEV Cell load_cell(const uint4 *gate, u64 idx) {
+    const uint4 a = gate[2 * idx], b = gate[2 * idx + 1];
+    Cell c;
+    c.l[0] = (u64)a.x | ((u64)a.y << 32); c.l[1] = (u64)a.z | ((u64)a.w << 32);
+    c.l[2] = (u64)b.x | ((u64)b.y << 32); c.l[3] = (u64)b.z | ((u64)b.w << 32);
+    return c;
+}
+DEV bool narrow(const Cell &c) { return (c.l[1] | c.l[2] | c.l[3]) == 0; }
+DEV bool same(const Cell &a, const Cell &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+DEV Cell small(u64 v) { Cell c; c.l[0] = v; c.l[1] = c.l[2] = c.l[3] = 0; return c; }
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
+    const u64 blk = blockIdx.x;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const uint4 *gate = reinterpret_cast<const uint4 *>(p.gate);
+    const u64 g0 = blk * (u64)p.gate_cells;
+    const uint8_t *bytes = p.blocks + 64 * blk;
+    const u32 *pre = p.pre_states + 8 * blk;
+    u32 bad = 0;
+    u32 first = 0xffffffffu, first_class = 0;
+
+    // a cell by structure id: stream cell or one of the cells outside the block's stream
+    auto cell_of = [&](int64_t id, bool &known) -> Cell {
+        known = true;
+        if (id >= 0) return load_cell(gate, g0 + (u64)id);
+        if (id >= -64) return small(bytes[-1 - id]);                        // input byte k = -1 - id
+        if (id <= -100 && id >= -107) return small(pre[-100 - id]);          // pre-state word
+        if (id == -1000) return small(0);                                    // the Context's zero cell
+        known = false;                                                       // a halo2-base witness outside the stream
+        return small(0);
+    };
+    auto fail = [&](u32 cls, u32 at) { bad++; if (at < first) { first = at; first_class = cls; } };
+
+    // 1. per cell: fixed constants and QuantumCell::Existing copies
+    for (u32 c = tid; c < p.gate_cells; c += nt) {
+        const uint8_t k = p.kind[c];
+        if (k == 0) continue;
+        const Cell v = load_cell(gate, g0 + c);
+        if (k == 1) { if (!same(v, small((u64)p.ref[c]))) fail(VERIFY_CONSTANT, c); }
+        else { bool known; const Cell w = cell_of(p.ref[c], known); if (known && !same(v, w)) fail(VERIFY_COPY, c); }
+    }
+    // 2. gate rows x0 + x1*x2 = x3 (mod p).  All-narrow rows are exact in 128 bits; the only rows with a
+    //    full-width cell are the negations of ch: [a, p-a, 1, 0] and [M, p-a, 1, M-a] (compression.rs:320-335)
+    for (u32 r = tid; r < p.n_rows; r += nt) {
+        const u32 c = p.gate_rows[r];
+        const Cell x0 = load_cell(gate, g0 + c), x1 = load_cell(gate, g0 + c + 1), x2 = load_cell(gate, g0 + c + 2),
+                   x3 = load_cell(gate, g0 + c + 3);
+        bool ok;
+        if (narrow(x0) && narrow(x1) && narrow(x2) && narrow(x3)) {
+            const unsigned __int128 s = (unsigned __int128)x1.l[0] * x2.l[0] + x0.l[0];
+            ok = (u64)(s >> 64) == 0 && (u64)s == x3.l[0];
+        } else {
+            const u64 P0 = 0x43e1f593f0000001ull, P1 = 0x2833e84879b97091ull, P2 = 0xb85045b68181585dull, P3 = 0x30644e72e131a029ull;
+            const u64 a = P0 - x1.l[0];                                      // x1 = p - a
+            ok = narrow(x0) && narrow(x3) && narrow(x2) && x2.l[0] == 1 && x1.l[1] == P1 && x1.l[2] == P2 && x1.l[3] == P3 &&
+                 a >= 1 && a <= 0x55555555ull && x0.l[0] >= a && x0.l[0] - a == x3.l[0];
+        }
+        if (!ok) fail(VERIFY_GATE_ROW, c);
+    }
+    // 3. assert_equal / range_check accumulator copies
+    for (u32 i = tid; i < p.n_assert_eq; i += nt) {
+        bool ka, kb;
+        const Cell a = cell_of(p.assert_eq[2 * i], ka), b = cell_of(p.assert_eq[2 * i + 1], kb);
+        if (ka && kb && !same(a, b)) fail(VERIFY_ASSERT_EQ, (u32)(p.assert_eq[2 * i] >= 0 ? p.assert_eq[2 * i] : p.assert_eq[2 * i + 1]));
+    }
+    // 4. range_check bounds
+    for (u32 i = tid; i < p.n_range; i += nt) {
+        bool known;
+        const Cell v = cell_of(p.range[2 * i], known);
+        const int64_t bits = p.range[2 * i + 1];
+        if (known && !(narrow(v) && (bits >= 64 || (v.l[0] >> bits) == 0))) fail(VERIFY_RANGE, (u32)p.range[2 * i]);
+    }
+    // 5. spread chip: limb call n of this block is absolute call N = cursor0 + blk*LC + n -> column N % ncols,
+    //    row N / ncols (spread.rs:202-231); the cells are tied to gate cells and form a row of the spread table
+    if (p.chip_dense) {
+        const uint4 *cd = reinterpret_cast<const uint4 *>(p.chip_dense), *csp = reinterpret_cast<const uint4 *>(p.chip_spread);
+        const u64 row0 = p.cursor0 / p.ncols;
+        for (u32 n = tid; n < p.limb_calls; n += nt) {
+            const u64 N = p.cursor0 + blk * (u64)p.limb_calls + n;
+            const u64 at = (N % p.ncols) * (u64)p.chip_col_stride + (N / p.ncols - row0);
+            const Cell d = load_cell(cd, at), sp = load_cell(csp, at);
+            bool k1, k2;
+            const Cell gd = cell_of(p.chip[2 * n], k1), gs = cell_of(p.chip[2 * n + 1], k2);
+            const bool ok = same(d, gd) && same(sp, gs) && narrow(d) && narrow(sp) && d.l[0] < (1ull << p.num_bits_lookup) &&
+                            (u64)spread16((u32)d.l[0]) == sp.l[0];
+            if (!ok) fail(VERIFY_CHIP, (u32)p.chip[2 * n + 1]);
+        }
+    }
+    // 6. lookup-advice column: entry j copies its source cell and is a 16-bit range-table entry
+    if (p.lookup) {
+        const uint4 *lk = reinterpret_cast<const uint4 *>(p.lookup);
+        for (u32 j = tid; j < p.lookup_cells; j += nt) {
+            bool known;
+            const Cell src = cell_of(p.lookup_src[j], known);
+            const Cell v = load_cell(lk, blk * (u64)p.lookup_cells + j);
+            if (!(narrow(v) && v.l[0] < 65536 && (!known || same(v, src)))) fail(VERIFY_LOOKUP, j);
+        }
+    }
+    // 7. next-state words
+    if (p.next_states && tid < 8) {
+        bool known;
+        const Cell v = cell_of(p.next_state_cells[tid], known);
+        if (!same(v, small(p.next_states[8 * blk + tid]))) fail(VERIFY_NEXT_STATE, (u32)p.next_state_cells[tid]);
+    }
+    if (bad) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&p.report->violations), (unsigned long long)bad);
+        // first failing (block, cell): smallest packed key wins
+        const unsigned long long key = (blk << 32) | first;
+        const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
+        if (key < old) p.report->first_class = first_class;      // best effort: the class of (one of) the earliest failures
+    }
+}
+
+hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(hsw_verify_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace hsw

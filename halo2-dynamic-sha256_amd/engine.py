@@ -170,6 +170,26 @@ class WitnessEngine:
         out["_keep"] = keep
         return out
 
+    def verify_blocks(self, blocks, pre_states, out, cursor0=0, lookup=None, check_chip=True, check_next=True):
+        """hsw_verify_blocks: on-device check of the streams in `out` (as written by witness_blocks for
+        these inputs) against the gadget's constraint system.  Returns the report as a dict."""
+        a = N.WitnessArgs()
+        n = blocks.numel() // 64
+        a.d_blocks, a.d_pre_states, a.n_blocks = blocks.data_ptr(), pre_states.data_ptr(), n
+        a.spread_cursor0, a.d_gate = cursor0, out["gate"].data_ptr()
+        if check_chip:
+            a.d_chip_dense, a.d_chip_spread = out["dense"].data_ptr(), out["spread"].data_ptr()
+            a.chip_col_stride = out["dense"].shape[1]
+        if check_next and out.get("next_states") is not None:
+            a.d_next_states = out["next_states"].data_ptr()
+        if lookup is not None:
+            a.d_lookup = lookup.data_ptr()
+        rep = N.VerifyReport()
+        self._ok(self.lib.hsw_verify_blocks(self.h, C.byref(a), C.byref(rep)))
+        return dict(violations=int(rep.violations), checks=int(rep.checks), first_block=int(rep.first_block),
+                    first_cell=int(rep.first_cell), first_class=N.VerifyReport.CLASSES.get(int(rep.first_class)),
+                    kernel_ms=float(rep.kernel_ms))
+
     def host_empty(self, shape):
         """numpy uint64 array in page-locked memory (hsw_host_alloc); the allocation lives as long as
         the array (it is kept alive through the array's base object)."""

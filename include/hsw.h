@@ -230,6 +230,33 @@ int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, ui
                         int64_t *cell_ref, uint32_t *gate_rows, int64_t *assert_eq, int64_t *range,
                         int64_t *lookup_src, int64_t *chip, int64_t *next_state);
 
+/* On-device check of a block witness against the gadget's constraint system -- what MockProver::verify
+ * checks for the path (lib.rs:525-526): every gate row, copy constraint (Existing cells, assert_equal),
+ * fixed constant, range_check bound, spread-chip cell (tied to its gate cell; (dense, spread) a row of the
+ * spread table), lookup-column copy and next-state word, with the block bytes and pre-states entering
+ * only through the cells they are copy-constrained to.  No value is recomputed from the inputs, so a
+ * stream that passes IS the witness of its inputs (every cell is forced by those constraints).  Takes
+ * the buffers of a hsw_witness_blocks(_ex) call (canonical cells, plain linear stream: no pack / frames;
+ * chip, lookup and next-state pointers may be NULL = not checked).  Synchronous. */
+#define HSW_VERIFY_CONSTANT   1u
+#define HSW_VERIFY_COPY       2u
+#define HSW_VERIFY_GATE_ROW   3u
+#define HSW_VERIFY_ASSERT_EQ  4u
+#define HSW_VERIFY_RANGE      5u
+#define HSW_VERIFY_CHIP       6u
+#define HSW_VERIFY_LOOKUP     7u
+#define HSW_VERIFY_NEXT_STATE 8u
+typedef struct hsw_verify_report {
+    uint64_t violations;       /* 0 = the stream satisfies the constraint system */
+    uint64_t checks;           /* individual constraints evaluated */
+    uint64_t first_block;      /* earliest failure (valid if violations != 0) */
+    int64_t first_cell;        /* block-relative gate cell (lookup entry for HSW_VERIFY_LOOKUP) */
+    uint32_t first_class;      /* HSW_VERIFY_* */
+    float kernel_ms;
+} hsw_verify_report;
+struct hsw_witness_args;
+int hsw_verify_blocks(hsw_engine *e, const struct hsw_witness_args *args, hsw_verify_report *report);
+
 typedef struct hsw_witness_args {
     const uint8_t *d_blocks;       /* as hsw_witness_blocks */
     const uint32_t *d_pre_states;

@@ -158,6 +158,18 @@ pub const HSW_KIND_WITNESS: u8 = 0;
 pub const HSW_KIND_CONSTANT: u8 = 1;
 pub const HSW_KIND_EXISTING: u8 = 2;
 
+/// Result of `hsw_verify_blocks`.
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_verify_report {
+    pub violations: u64,
+    pub checks: u64,
+    pub first_block: u64,
+    pub first_cell: i64,
+    pub first_class: u32,
+    pub kernel_ms: f32,
+}
+
 pub const HSW_CELL_TARGET: i64 = -3000;
 pub const HSW_CELL_STATE0: i64 = -4000;
 
@@ -265,6 +277,7 @@ extern "C" {
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
+    pub fn hsw_verify_blocks(e: *mut hsw_engine, args: *const hsw_witness_args, report: *mut hsw_verify_report) -> c_int;
     pub fn hsw_frame_structure(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                                section: c_int, counts: *mut hsw_frame_structure_counts, cell_kind: *mut u8,
                                cell_ref: *mut i64, gate_rows: *mut u32, assert_eq: *mut i64,

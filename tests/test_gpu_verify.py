@@ -1,0 +1,134 @@
+"""hsw_verify_blocks: the product's own on-device MockProver-style check (gate rows, copy constraints,
+constants, ranges, chip cells + spread table, lookup copies, next states) -- accepts what the kernels
+write, and pins down single corrupted cells of every constraint class."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 256, (n, 64), dtype=np.uint8),
+            rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32))
+
+
+def _gen(eng, n, seed, cursor0=0):
+    import torch
+    blocks, pre = _inputs(n, seed)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    out = eng.witness_blocks(tb, tp, cursor0=cursor0)
+    eng.synchronize()
+    return tb, tp, out
+
+
+def test_verify_accepts_generated_streams(engine_factory, hsw):
+    eng = engine_factory(8, 2)
+    tb, tp, out = _gen(eng, 6, 11, cursor0=4)
+    rep = eng.verify_blocks(tb, tp, out, cursor0=4)
+    # per block: 13,638 constants + 30,550 - 3,850 Existing copies ... counted by the library; at least these
+    assert rep["violations"] == 0 and rep["checks"] >= 6 * (13510 + 3850 + 2424 + 4 * 4120 + 8 + 40000)
+    # chip / next-state checks are optional
+    rep2 = eng.verify_blocks(tb, tp, out, cursor0=4, check_chip=False, check_next=False)
+    assert rep2["violations"] == 0 and rep2["checks"] == rep["checks"] - 6 * (4 * 4120 + 8)
+
+
+@pytest.mark.parametrize("bits,ncols", [(16, 1), (4, 3), (8, 5)])
+def test_verify_other_shapes(engine_factory, bits, ncols):
+    eng = engine_factory(bits, ncols)
+    tb, tp, out = _gen(eng, 3, 5 + bits, cursor0=7)
+    assert eng.verify_blocks(tb, tp, out, cursor0=7)["violations"] == 0
+
+
+def test_verify_pins_single_corruptions(engine_factory, oracle, hsw):
+    """Flip one cell of each constraint class; the report names block, cell and class."""
+    import torch
+    eng = engine_factory(8, 2)
+    tb, tp, out = _gen(eng, 4, 99)
+    st = hsw._native.block_structure(eng.shape)
+    G = eng.G
+    kind, ref = st["kind"], st["ref"]
+    const_cell = int(np.nonzero(kind == 1)[0][100])
+    copy_cell = int(np.nonzero((kind == 2) & (ref >= 0))[0][500])
+    row = int(st["gate_rows"][7000])
+    witness_out = row + 3                                   # the output of a gate row: a pure witness
+    range_cell = int(st["range"][50][0])
+    cases = [(2, const_cell, "constant"), (1, copy_cell, "copy"), (3, witness_out, None), (0, range_cell, None)]
+    for blk, cell, want in cases:
+        g = out["gate"]
+        saved = g[blk * G + cell].clone()
+        g[blk * G + cell, 0] += 1
+        rep = eng.verify_blocks(tb, tp, out)
+        assert rep["violations"] >= 1, (blk, cell)
+        assert rep["first_block"] == blk
+        if want:      # the earliest failing cell: the cell itself, or the start of the gate row it sits in
+            assert rep["first_class"] in (want, "gate row") and cell - 3 <= rep["first_cell"] <= cell
+        g[blk * G + cell] = saved
+        assert eng.verify_blocks(tb, tp, out)["violations"] == 0
+    # a chip cell, a next-state word, an input byte, a pre-state word
+    d = out["dense"]
+    saved = d[1, 37].clone(); d[1, 37, 0] ^= 1
+    rep = eng.verify_blocks(tb, tp, out)
+    assert rep["violations"] >= 1 and rep["first_class"] == "chip"
+    d[1, 37] = saved
+    ns = out["next_states"]
+    ns[2, 3] += 1
+    rep = eng.verify_blocks(tb, tp, out)
+    assert rep["violations"] == 1 and rep["first_class"] == "next state" and rep["first_block"] == 2
+    ns[2, 3] -= 1
+    tb2 = tb.clone(); tb2[1, 17] ^= 0x40
+    rep = eng.verify_blocks(tb2, tp, out)
+    assert rep["violations"] >= 1 and rep["first_block"] == 1 and rep["first_class"] in ("copy", "gate row")
+    tp2 = tp.clone(); tp2[3, 5] ^= 1
+    rep = eng.verify_blocks(tb, tp2, out)
+    assert rep["violations"] >= 1 and rep["first_block"] == 3
+    assert eng.verify_blocks(tb, tp, out)["violations"] == 0
+
+
+def test_verify_internals_mode_with_lookup_column(hsw):
+    import torch
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+    blocks, pre = _inputs(5, 3)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    out = eng.witness_blocks_ex(tb, tp, cursor0=2, want_lookup=True)
+    eng.synchronize()
+    rep = eng.verify_blocks(tb, tp, out, cursor0=2, lookup=out["lookup"])
+    assert rep["violations"] == 0
+    lk = out["lookup"]
+    lk[3 * eng.lookup_cells + 1000, 0] += 1
+    rep = eng.verify_blocks(tb, tp, out, cursor0=2, lookup=lk)
+    assert rep["violations"] == 1 and rep["first_class"] == "lookup" and rep["first_block"] == 3 and rep["first_cell"] == 1000
+    eng.close()
+
+
+def test_verify_rejects_what_it_cannot_check(engine_factory, hsw):
+    import ctypes as C
+    N = hsw._native
+    eng = engine_factory(8, 2)
+    tb, tp, out = _gen(eng, 1, 1)
+    a = N.WitnessArgs()
+    a.d_blocks, a.d_pre_states, a.n_blocks, a.d_gate = tb.data_ptr(), tp.data_ptr(), 1, out["gate"].data_ptr()
+    rep = N.VerifyReport()
+    a.flags = N.HSW_REPR_MONTGOMERY
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_UNSUPPORTED
+    a.flags = 0
+    a.frame_every = 1
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_UNSUPPORTED
+    a.frame_every = 0
+    a.d_lookup = out["gate"].data_ptr()
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
+    a.d_lookup = None
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations == 0
+
+
+def test_verify_full_batch(engine_factory):
+    """configs[2]: all 4,096 blocks (9.77 GB of cells), checked in HBM in a few milliseconds."""
+    eng = engine_factory(8, 2)
+    tb, tp, out = _gen(eng, 4096, 0xC3)
+    rep = eng.verify_blocks(tb, tp, out)
+    assert rep["violations"] == 0 and rep["checks"] > 2.5e8
+    assert rep["kernel_ms"] < 50
+    out["gate"][4000 * eng.G + 12345, 0] ^= 1
+    rep = eng.verify_blocks(tb, tp, out)
+    assert rep["violations"] >= 1 and rep["first_block"] == 4000 and rep["first_cell"] in (12345, 12344, 12343, 12342)
