@@ -59,6 +59,7 @@ struct hsw_engine {
     void *d_structure = nullptr;
     hsw::VerifyParams verify_tpl{};      // structure pointers / counts filled in
     uint64_t verify_checks_per_block = 0;
+    int verify_slices = 0;               // workgroups per block in hsw_verify_kernel; 0 = default
     hsw::VerifyReport *d_report = nullptr;
 };
 
@@ -316,6 +317,11 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
             return set_err(e, HSW_ERR_INVALID_ARG, "parts must be 0 (auto), 1, 2, 4, 8, 16 or 32");
         e->parts = (int)value;
+        return HSW_OK;
+    }
+    if (std::strcmp(name, "verify_slices") == 0) {
+        if (value < 0 || value > 256) return set_err(e, HSW_ERR_INVALID_ARG, "verify_slices must be 0 (default) .. 256");
+        e->verify_slices = (int)value;
         return HSW_OK;
     }
     if (std::strcmp(name, "split") == 0) {
@@ -611,8 +617,15 @@ static int ensure_structure(hsw_engine *e) {
     p.n_range = (uint32_t)(st.range.size() / 2);
     p.limb_calls = (uint32_t)(st.chip.size() / 2);
     p.lookup_cells = (uint32_t)st.lookup_src.size();
+    // the kernel checks constants / copies while it walks the gate rows: every such cell must sit in one
+    std::vector<uint8_t> in_row(st.kind.size(), 0);
+    for (uint32_t r : st.gate_rows) for (int j = 0; j < 4; j++) in_row[r + j] = 1;
     uint64_t fixed = 0;
-    for (uint8_t k : st.kind) fixed += k != 0;
+    for (size_t c = 0; c < st.kind.size(); c++) {
+        if (st.kind[c] != 0 && !in_row[c]) { (void)hipFree(d); (void)hipFree(e->d_report); e->d_structure = nullptr; e->d_report = nullptr;
+                                             return set_err(e, HSW_ERR_UNSUPPORTED, "structure has a fixed / copied cell outside every gate row"); }
+        fixed += st.kind[c] != 0;
+    }
     e->verify_checks_per_block = fixed + p.n_rows + p.n_assert_eq + p.n_range;
     return HSW_OK;
 }
@@ -636,6 +649,7 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     p.cursor0 = args->spread_cursor0; p.chip_col_stride = args->chip_col_stride;
     p.ncols = e->shape.num_advice_columns; p.num_bits_lookup = e->shape.num_bits_lookup;
     p.report = e->d_report;
+    p.slices = e->verify_slices > 0 ? (uint32_t)e->verify_slices : 1u;   // more slices measured no better (tools/verify_slices.py)
     const hsw::VerifyReport zero{0, ~0ull, 0, 0};
     hipError_t he = hipMemcpyAsync(e->d_report, &zero, sizeof zero, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) he = hipEventRecord(e->ev0, e->stream);

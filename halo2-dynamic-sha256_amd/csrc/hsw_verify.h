@@ -31,6 +31,7 @@ struct VerifyParams {
     uint64_t cursor0;
     uint64_t chip_col_stride;
     uint32_t ncols, num_bits_lookup;
+    uint32_t slices;               // workgroups per block
     // the structure (device copies of hsw::BlockStructure)
     uint32_t gate_cells, n_rows, n_assert_eq, n_range, limb_calls, lookup_cells;
     const uint8_t *kind;

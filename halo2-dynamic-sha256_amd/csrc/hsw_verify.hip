@@ -7,8 +7,10 @@
 // with the block bytes and the pre-state entering only through the external cells they are
 // copy-constrained to.  The structure is the product's own (csrc/hsw_structure.hpp); no value is
 // recomputed from the inputs, so a stream that passes is the witness of its inputs by the uniqueness
-// argument of SURVEY 8c.  Canonical 32-byte cells.  One 256-thread workgroup per block; the kernel reads
-// the stream once (plus neighbouring re-reads that hit L2): HBM-read bound.
+// argument of SURVEY 8c.  Canonical 32-byte cells.  One pass over the gate rows checks the row equation and,
+// on the same four loads, the constants and copies among the row's cells; the scattered 32-byte loads of
+// copy sources (a 128-byte line each) are what bounds it: ~3.8 ms for 4,096 blocks, 2.2x the time it took
+// to write them.  `slices` workgroups may share a block (measured: no better than one).
 #include "hsw_expand.hpp"
 #include "hsw_verify.h"
 
@@ -32,8 +34,8 @@ DEV Cell small(u64 v) { Cell c; c.l[0] = v; c.l[1] = c.l[2] = c.l[3] = 0; return
 }  // namespace
 
 __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
-    const u64 blk = blockIdx.x;
-    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u64 blk = blockIdx.x / p.slices;
+    const u32 tid = (blockIdx.x % p.slices) * blockDim.x + threadIdx.x, nt = p.slices * blockDim.x;
     const uint4 *gate = reinterpret_cast<const uint4 *>(p.gate);
     const u64 g0 = blk * (u64)p.gate_cells;
     const uint8_t *bytes = p.blocks + 64 * blk;
@@ -53,31 +55,33 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     };
     auto fail = [&](u32 cls, u32 at) { bad++; if (at < first) { first = at; first_class = cls; } };
 
-    // 1. per cell: fixed constants and QuantumCell::Existing copies
-    for (u32 c = tid; c < p.gate_cells; c += nt) {
-        const uint8_t k = p.kind[c];
-        if (k == 0) continue;
-        const Cell v = load_cell(gate, g0 + c);
-        if (k == 1) { if (!same(v, small((u64)p.ref[c]))) fail(VERIFY_CONSTANT, c); }
-        else { bool known; const Cell w = cell_of(p.ref[c], known); if (known && !same(v, w)) fail(VERIFY_COPY, c); }
-    }
-    // 2. gate rows x0 + x1*x2 = x3 (mod p).  All-narrow rows are exact in 128 bits; the only rows with a
-    //    full-width cell are the negations of ch: [a, p-a, 1, 0] and [M, p-a, 1, M-a] (compression.rs:320-335)
+    // 1 + 2. gate rows x0 + x1*x2 = x3 (mod p), and -- on the same four loads -- what each of the row's cells
+    //    must be: a fixed constant or a QuantumCell::Existing copy (every such cell sits in a gate row; the
+    //    host checks that when it uploads the structure).  All-narrow rows are exact in 128 bits; the only
+    //    rows with a full-width cell are the negations of ch: [a, p-a, 1, 0] and [M, p-a, 1, M-a]
+    //    (compression.rs:320-335)
     for (u32 r = tid; r < p.n_rows; r += nt) {
         const u32 c = p.gate_rows[r];
-        const Cell x0 = load_cell(gate, g0 + c), x1 = load_cell(gate, g0 + c + 1), x2 = load_cell(gate, g0 + c + 2),
-                   x3 = load_cell(gate, g0 + c + 3);
+        Cell x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = load_cell(gate, g0 + c + j);
         bool ok;
-        if (narrow(x0) && narrow(x1) && narrow(x2) && narrow(x3)) {
-            const unsigned __int128 s = (unsigned __int128)x1.l[0] * x2.l[0] + x0.l[0];
-            ok = (u64)(s >> 64) == 0 && (u64)s == x3.l[0];
+        if (narrow(x[0]) && narrow(x[1]) && narrow(x[2]) && narrow(x[3])) {
+            const unsigned __int128 s = (unsigned __int128)x[1].l[0] * x[2].l[0] + x[0].l[0];
+            ok = (u64)(s >> 64) == 0 && (u64)s == x[3].l[0];
         } else {
             const u64 P0 = 0x43e1f593f0000001ull, P1 = 0x2833e84879b97091ull, P2 = 0xb85045b68181585dull, P3 = 0x30644e72e131a029ull;
-            const u64 a = P0 - x1.l[0];                                      // x1 = p - a
-            ok = narrow(x0) && narrow(x3) && narrow(x2) && x2.l[0] == 1 && x1.l[1] == P1 && x1.l[2] == P2 && x1.l[3] == P3 &&
-                 a >= 1 && a <= 0x55555555ull && x0.l[0] >= a && x0.l[0] - a == x3.l[0];
+            const u64 a = P0 - x[1].l[0];                                    // x1 = p - a
+            ok = narrow(x[0]) && narrow(x[3]) && narrow(x[2]) && x[2].l[0] == 1 && x[1].l[1] == P1 && x[1].l[2] == P2 &&
+                 x[1].l[3] == P3 && a >= 1 && a <= 0x55555555ull && x[0].l[0] >= a && x[0].l[0] - a == x[3].l[0];
         }
         if (!ok) fail(VERIFY_GATE_ROW, c);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint8_t k = p.kind[c + j];
+            if (k == 1) { if (!same(x[j], small((u64)p.ref[c + j]))) fail(VERIFY_CONSTANT, c + j); }
+            else if (k == 2) { bool known; const Cell w = cell_of(p.ref[c + j], known); if (known && !same(x[j], w)) fail(VERIFY_COPY, c + j); }
+        }
     }
     // 3. assert_equal / range_check accumulator copies
     for (u32 i = tid; i < p.n_assert_eq; i += nt) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
 
 hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(hsw_verify_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hsw_verify_kernel, dim3((unsigned)(n_blocks * p.slices)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
