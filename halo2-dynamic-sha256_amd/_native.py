@@ -134,6 +134,7 @@ SYMBOLS = (
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
+    "hsw_verify_frames", "hsw_gadget_verify",
 )
 
 
@@ -247,6 +248,11 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_verify_frames.restype = C.c_int
+        L.hsw_verify_frames.argtypes = [vp, C.POINTER(FrameDesc), C.c_size_t, vp, vp, vp, vp, vp, C.POINTER(PackPlan),
+                                        C.c_uint32, C.POINTER(VerifyReport)]
+        L.hsw_gadget_verify.restype = C.c_int
+        L.hsw_gadget_verify.argtypes = [vp, C.POINTER(VerifyReport)]
         L.hsw_verify_blocks.restype = C.c_int
         L.hsw_verify_blocks.argtypes = [vp, C.POINTER(WitnessArgs), C.POINTER(VerifyReport)]
         L.hsw_frame_structure.restype = C.c_int

@@ -636,7 +636,9 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     if (args->n_blocks == 0) return HSW_OK;
     if (!args->d_gate || !args->d_blocks || !args->d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
     if (args->flags & HSW_REPR_MASK) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks canonical cells");
-    if (args->pack || args->frame_every) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks plain linear streams");
+    if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    if (args->frame_every && e->mode != HSW_MODE_HALO2_INTERNALS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
     if ((args->d_chip_dense == nullptr) != (args->d_chip_spread == nullptr)) return set_err(e, HSW_ERR_INVALID_ARG, "both chip families or none");
     if (args->d_lookup && e->mode != HSW_MODE_HALO2_INTERNALS) return set_err(e, HSW_ERR_INVALID_ARG, "d_lookup needs HSW_MODE_HALO2_INTERNALS");
     DeviceScope ds(e->device);
@@ -648,6 +650,10 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     p.blocks = args->d_blocks; p.pre_states = args->d_pre_states; p.next_states = args->d_next_states;
     p.cursor0 = args->spread_cursor0; p.chip_col_stride = args->chip_col_stride;
     p.ncols = e->shape.num_advice_columns; p.num_bits_lookup = e->shape.num_bits_lookup;
+    p.gate_cell0 = p.lookup_cell0 = 0;
+    p.frame_every = args->frame_every; p.frame_cells = args->frame_cells; p.frame_lookups = args->frame_lookups;
+    p.n_breaks = args->pack ? args->pack->n_breaks : 0;
+    for (uint32_t k = 0; k < p.n_breaks; k++) { p.break_cell[k] = args->pack->break_cell[k]; p.break_gap[k] = args->pack->break_gap[k]; }
     p.report = e->d_report;
     p.slices = e->verify_slices > 0 ? (uint32_t)e->verify_slices : 1u;   // more slices measured no better (tools/verify_slices.py)
     const hsw::VerifyReport zero{0, ~0ull, 0, 0};
@@ -667,6 +673,106 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     if (args->d_lookup) per_block += 2ull * p.lookup_cells;
     if (args->d_next_states) per_block += 8;
     report->checks = per_block * args->n_blocks;
+    if (got.violations) {
+        report->first_block = got.first_key >> 32;
+        report->first_cell = (int64_t)(got.first_key & 0xffffffffu);
+        report->first_class = got.first_class;
+    }
+    return HSW_OK;
+}
+
+int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                      const uint32_t *d_pre_states, const uint32_t *d_next_states, const void *d_gate,
+                      const void *d_lookup, const hsw_pack_plan *pack, uint32_t flags, hsw_verify_report *report) {
+    if (!e || !report) return HSW_ERR_INVALID_ARG;
+    std::memset(report, 0, sizeof *report);
+    if (n == 0) return HSW_OK;
+    if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    if (e->mode != HSW_MODE_HALO2_INTERNALS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
+    if (flags & HSW_REPR_MASK) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_frames checks canonical cells");
+    if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    for (size_t i = 0; i < n; i++) {
+        if (descs[i].n_blocks == 0 || descs[i].n_blocks != descs[0].n_blocks ||
+            (descs[i].is_input_range_check != 0) != (descs[0].is_input_range_check != 0))
+            return set_err(e, HSW_ERR_INVALID_ARG, "one call verifies equally shaped digests (same n_blocks, same range-check setting)");
+        if ((uint64_t)descs[i].num_round != (descs[i].input_len + 9 + 63) / 64 || descs[i].precomputed_round > descs[i].num_round)
+            return set_err(e, HSW_ERR_INVALID_ARG, "inconsistent digest descriptor");
+    }
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (!e->d_report) {
+        hipError_t h0 = hipMalloc((void **)&e->d_report, sizeof(hsw::VerifyReport));
+        if (h0 != hipSuccess) return set_err(e, HSW_ERR_NOMEM, "hipMalloc", h0);
+    }
+    // structures of this shape + the descriptors, in one temporary device buffer
+    hsw::FrameStructureBuilder fb;
+    const hsw::FrameStructure st[2] = {fb.prologue((uint64_t)descs[0].n_blocks * 64, descs[0].is_input_range_check != 0),
+                                       fb.epilogue(descs[0].n_blocks)};
+    std::vector<hsw::FrameDesc> hd(n);
+    for (size_t i = 0; i < n; i++) {
+        hsw::FrameDesc &o = hd[i];
+        const hsw_frame_desc &d = descs[i];
+        o.input_len = d.input_len; o.first_block = d.first_block; o.prologue_cell = d.prologue_cell; o.epilogue_cell = d.epilogue_cell;
+        o.prologue_lookup = d.prologue_lookup; o.epilogue_lookup = d.epilogue_lookup; o.zero_cell = d.zero_cell;
+        o.n_blocks = d.n_blocks; o.num_round = d.num_round; o.precomputed_round = d.precomputed_round;
+        o.range_check_inputs = d.is_input_range_check ? 1u : 0u;
+    }
+    std::vector<uint8_t> h;
+    auto put = [&](const void *src, size_t bytes) { const size_t at = (h.size() + 7) & ~(size_t)7; h.resize(at + bytes); if (bytes) std::memcpy(h.data() + at, src, bytes); return at; };
+    size_t off[2][7];
+    for (int s2 = 0; s2 < 2; s2++) {
+        off[s2][0] = put(st[s2].kind.data(), st[s2].kind.size());
+        off[s2][1] = put(st[s2].ref.data(), st[s2].ref.size() * 8);
+        off[s2][2] = put(st[s2].gate_rows.data(), st[s2].gate_rows.size() * 4);
+        off[s2][3] = put(st[s2].assert_eq.data(), st[s2].assert_eq.size() * 8);
+        off[s2][4] = put(st[s2].assert_const.data(), st[s2].assert_const.size() * 8);
+        off[s2][5] = put(st[s2].range.data(), st[s2].range.size() * 8);
+        off[s2][6] = put(st[s2].lookup_src.data(), st[s2].lookup_src.size() * 8);
+    }
+    const size_t o_desc = put(hd.data(), hd.size() * sizeof(hsw::FrameDesc));
+    uint8_t *dbuf = nullptr;
+    hipError_t he = hipMalloc((void **)&dbuf, h.size());
+    if (he != hipSuccess) return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "hipMalloc", he);
+    hsw::FrameVerifyParams p{};
+    p.descs = reinterpret_cast<const hsw::FrameDesc *>(dbuf + o_desc);
+    p.gate = d_gate; p.lookup = d_lookup; p.blocks = d_blocks; p.pre_states = d_pre_states; p.next_states = d_next_states;
+    p.n_breaks = pack ? pack->n_breaks : 0;
+    for (uint32_t k = 0; k < p.n_breaks; k++) { p.break_cell[k] = pack->break_cell[k]; p.break_gap[k] = pack->break_gap[k]; }
+    uint64_t checks = 0;
+    for (int s2 = 0; s2 < 2; s2++) {
+        hsw::FrameVerifyParams::Section &S = s2 ? p.epi : p.pro;
+        S.cells = (uint32_t)st[s2].kind.size(); S.n_rows = (uint32_t)st[s2].gate_rows.size();
+        S.n_assert_eq = (uint32_t)(st[s2].assert_eq.size() / 2); S.n_assert_const = (uint32_t)(st[s2].assert_const.size() / 2);
+        S.n_range = (uint32_t)(st[s2].range.size() / 2); S.n_lookup = (uint32_t)st[s2].lookup_src.size();
+        S.kind = dbuf + off[s2][0];
+        S.ref = reinterpret_cast<const int64_t *>(dbuf + off[s2][1]);
+        S.gate_rows = reinterpret_cast<const uint32_t *>(dbuf + off[s2][2]);
+        S.assert_eq = reinterpret_cast<const int64_t *>(dbuf + off[s2][3]);
+        S.assert_const = reinterpret_cast<const int64_t *>(dbuf + off[s2][4]);
+        S.range = reinterpret_cast<const int64_t *>(dbuf + off[s2][5]);
+        S.lookup_src = reinterpret_cast<const int64_t *>(dbuf + off[s2][6]);
+        uint64_t fixed = 0;
+        for (uint8_t k : st[s2].kind) fixed += k != 0;
+        checks += fixed + S.n_rows + S.n_assert_eq + S.n_assert_const + S.n_range + (d_lookup ? 2ull * S.n_lookup : 0);
+    }
+    checks += 2 + 8 + 64ull * descs[0].n_blocks + 8ull * (descs[0].n_blocks - 1);      // facts and links
+    p.report = e->d_report;
+    const hsw::VerifyReport zero{0, ~0ull, 0, 0};
+    he = hipMemcpyAsync(dbuf, h.data(), h.size(), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->d_report, &zero, sizeof zero, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(e->ev0, e->stream);
+    if (he == hipSuccess) he = hsw::launch_verify_frames(p, n, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(e->ev1, e->stream);
+    hsw::VerifyReport got{};
+    if (he == hipSuccess) he = hipMemcpyAsync(&got, e->d_report, sizeof got, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipEventElapsedTime(&report->kernel_ms, e->ev0, e->ev1);
+    e->timed = false;
+    (void)hipFree(dbuf);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_verify_frames", he);
+    report->violations = got.violations;
+    report->checks = checks * n;
     if (got.violations) {
         report->first_block = got.first_key >> 32;
         report->first_cell = (int64_t)(got.first_key & 0xffffffffu);

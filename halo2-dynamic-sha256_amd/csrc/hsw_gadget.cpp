@@ -562,6 +562,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         }
         off += pl.max_variable_round;
     }
+    ctx.batches.push_back(Context::BatchRecord{cur_hash_idx, n, b0, batch_blocks, zero_copy});
     ctx.blocks_done += batch_blocks;
     if (ctx.whole) {
         ctx.gate_cursor = new_gate_cursor;
@@ -711,6 +712,7 @@ int hsw_gadget_reset(hsw_gadget *g) {
     c.num_limb_sum = 0;                 // spread.rs:70-71
     c.gate_cursor = c.lookup_cursor = 0;
     c.zero_loaded = false;
+    c.batches.clear();
     g->cfg.cur_hash_idx = 0;            // lib.rs:66
     g->results.clear();
     return HSW_OK;
@@ -780,8 +782,102 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) {
     c.lookup_cursor = lookup;
     c.zero_loaded = hash_idx > 0;
     g->cfg.cur_hash_idx = hash_idx;
+    c.batches.clear();
     g->results.clear();
     g->results.resize(hash_idx);        // keeps hash_idx -> result indexing of hsw_gadget_input_bytes
+    return HSW_OK;
+}
+
+int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
+    if (!g || !report) return HSW_ERR_INVALID_ARG;
+    std::memset(report, 0, sizeof *report);
+    hsw::Context &c = *g->ctx;
+    if (c.repr_flags & HSW_REPR_MASK) return HSW_ERR_UNSUPPORTED;              // canonical cells only
+    const size_t G = c.shape.gate_cells_per_block, cb = HSW_CELL_BYTES;
+    const uint32_t ncols = c.shape.num_advice_columns;
+    auto merge = [&](const hsw_verify_report &r) {
+        if (r.violations && !report->violations) {
+            report->first_block = r.first_block; report->first_cell = r.first_cell; report->first_class = r.first_class;
+        }
+        report->violations += r.violations; report->checks += r.checks; report->kernel_ms += r.kernel_ms;
+    };
+    hsw_pack_plan abs_plan{};
+    abs_plan.n_breaks = (uint32_t)c.break_cell.size();
+    for (size_t k = 0; k < c.break_cell.size(); k++) { abs_plan.break_cell[k] = c.break_cell[k]; abs_plan.break_gap[k] = c.break_gap[k]; }
+    for (const hsw::Context::BatchRecord &b : c.batches) {
+        const uint8_t *in_blocks = b.inputs_in_pinned ? c.dp_blocks : c.d_blocks;
+        const uint32_t *in_pre = b.inputs_in_pinned ? c.dp_pre : c.d_pre_states;
+        if (!c.whole) {
+            hsw_witness_args a{};
+            a.d_blocks = in_blocks + 64 * b.first_block; a.d_pre_states = in_pre + 8 * b.first_block; a.n_blocks = b.n_blocks;
+            a.spread_cursor0 = (uint64_t)b.first_block * c.shape.limb_calls_per_block;
+            const uint64_t row_shift = a.spread_cursor0 / ncols;
+            a.d_gate = static_cast<uint8_t *>(c.d_gate) + b.first_block * G * cb;
+            a.d_chip_dense = static_cast<uint8_t *>(c.d_chip_dense) + (size_t)row_shift * cb;
+            a.d_chip_spread = static_cast<uint8_t *>(c.d_chip_spread) + (size_t)row_shift * cb;
+            a.chip_col_stride = c.chip_col_stride;
+            a.d_next_states = c.d_next_states + 8 * b.first_block;
+            hsw_verify_report r;
+            const int rc = hsw_verify_blocks(c.engine, &a, &r);
+            if (rc != HSW_OK) return rc;
+            merge(r);
+            continue;
+        }
+        size_t ob = 0;
+        for (size_t i = 0; i < b.n_digests;) {                       // runs of equally sized digests, as generated
+            const hsw::AssignedHashResult &r0 = g->results[b.first_digest + i];
+            size_t j = i + 1;
+            while (j < b.n_digests && g->results[b.first_digest + j].n_blocks == r0.n_blocks) j++;
+            const size_t nb = r0.n_blocks, run_blocks = nb * (j - i), fb = b.first_block + ob;
+            hsw_frame_shape fs;
+            int rc = hsw_frame_query(&c.shape, nb * 64, g->cfg.is_input_range_check ? 1 : 0, &fs);
+            if (rc != HSW_OK) return rc;
+            hsw_witness_args a{};
+            a.d_blocks = in_blocks + 64 * fb; a.d_pre_states = in_pre + 8 * fb; a.n_blocks = run_blocks;
+            a.spread_cursor0 = (uint64_t)fb * c.shape.limb_calls_per_block;
+            const uint64_t row_shift = a.spread_cursor0 / ncols;
+            a.d_gate = static_cast<uint8_t *>(c.d_gate) + (size_t)r0.block_cell * cb;
+            a.d_chip_dense = static_cast<uint8_t *>(c.d_chip_dense) + (size_t)row_shift * cb;
+            a.d_chip_spread = static_cast<uint8_t *>(c.d_chip_spread) + (size_t)row_shift * cb;
+            a.chip_col_stride = c.chip_col_stride;
+            a.d_next_states = c.d_next_states + 8 * fb;
+            a.d_lookup = static_cast<uint8_t *>(c.d_lookup) + (size_t)r0.block_lookup * cb;
+            a.frame_every = nb; a.frame_cells = fs.epilogue_cells + fs.prologue_cells;
+            a.frame_lookups = fs.epilogue_lookups + fs.prologue_lookups;
+            hsw_pack_plan rel{};
+            if (c.max_rows) {
+                rel.n_breaks = abs_plan.n_breaks;
+                for (uint32_t k = 0; k < rel.n_breaks; k++) {
+                    rel.break_cell[k] = abs_plan.break_cell[k] > r0.block_cell ? abs_plan.break_cell[k] - r0.block_cell : 0;
+                    rel.break_gap[k] = abs_plan.break_gap[k];
+                }
+                a.pack = &rel;
+            }
+            hsw_verify_report r;
+            rc = hsw_verify_blocks(c.engine, &a, &r);
+            if (rc != HSW_OK) return rc;
+            merge(r);
+            std::vector<hsw_frame_desc> descs(j - i);
+            size_t blk = fb;
+            for (size_t k = i; k < j; k++) {
+                const hsw::AssignedHashResult &rk = g->results[b.first_digest + k];
+                hsw_frame_desc &d = descs[k - i];
+                d.input_len = rk.input_len; d.first_block = blk; d.n_blocks = (uint32_t)rk.n_blocks;
+                d.num_round = (uint32_t)rk.num_round; d.precomputed_round = (uint32_t)(rk.num_round - rk.target_round);
+                d.is_input_range_check = g->cfg.is_input_range_check ? 1u : 0u;
+                d.prologue_cell = rk.prologue_cell; d.epilogue_cell = rk.epilogue_cell;
+                d.prologue_lookup = rk.prologue_lookup; d.epilogue_lookup = rk.epilogue_lookup;
+                d.zero_cell = rk.block_cell == rk.prologue_cell + fs.prologue_cells + 1 ? rk.block_cell - 1 : ~0ull;
+                blk += rk.n_blocks;
+            }
+            rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), c.d_blocks, c.d_pre_states, c.d_next_states, c.d_gate,
+                                   c.d_lookup, c.max_rows ? &abs_plan : nullptr, 0, &r);
+            if (rc != HSW_OK) return rc;
+            merge(r);
+            ob += run_blocks;
+            i = j;
+        }
+    }
     return HSW_OK;
 }
 

@@ -13,6 +13,8 @@ enum : uint32_t {      // mirrors HSW_VERIFY_* of include/hsw.h
     VERIFY_CHIP = 6, VERIFY_LOOKUP = 7, VERIFY_NEXT_STATE = 8,
 };
 
+enum : int64_t { FS_ZERO = -1000, FS_TARGET = -3000, FS_STATE0 = -4000 };   // FrameStructure's external ids
+
 struct VerifyReport {              // device memory
     uint64_t violations;
     uint64_t first_key;            // (block << 32) | cell of the earliest failure; ~0 = none
@@ -32,6 +34,12 @@ struct VerifyParams {
     uint64_t chip_col_stride;
     uint32_t ncols, num_bits_lookup;
     uint32_t slices;               // workgroups per block
+    // whole-digest streams / column images: block b of the launch starts at stream cell
+    // gate_cell0 + b*gate_cells + (b / frame_every)*frame_cells (lookups alike); a stream cell i sits at
+    // i + the gaps of all breaks at or before it
+    uint64_t gate_cell0, lookup_cell0, frame_every, frame_cells, frame_lookups;
+    uint32_t n_breaks;
+    uint64_t break_cell[16], break_gap[16];
     // the structure (device copies of hsw::BlockStructure)
     uint32_t gate_cells, n_rows, n_assert_eq, n_range, limb_calls, lookup_cells;
     const uint8_t *kind;
@@ -42,6 +50,27 @@ struct VerifyParams {
 };
 
 hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream);
+
+struct FrameDesc;
+// The frames of `n` equally shaped digests (hsw_frame.hpp) against their structure (hsw_structure.hpp:
+// FrameStructure of the prologue and of the epilogue, uploaded by the host).
+struct FrameVerifyParams {
+    const FrameDesc *descs;
+    const void *gate, *lookup;     // stream origins (lookup may be null)
+    const uint8_t *blocks;
+    const uint32_t *pre_states, *next_states;
+    uint32_t n_breaks;
+    uint64_t break_cell[16], break_gap[16];
+    struct Section {
+        uint32_t cells, n_rows, n_assert_eq, n_assert_const, n_range, n_lookup;
+        const uint8_t *kind;
+        const int64_t *ref;
+        const uint32_t *gate_rows;
+        const int64_t *assert_eq, *assert_const, *range, *lookup_src;
+    } pro, epi;
+    VerifyReport *report;
+};
+hipError_t launch_verify_frames(const FrameVerifyParams &p, size_t n_digests, hipStream_t stream);
 
 }  // namespace hsw
 #endif

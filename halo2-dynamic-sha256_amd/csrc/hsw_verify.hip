@@ -12,6 +12,7 @@
 // copy sources (a 128-byte line each) are what bounds it: ~3.8 ms for 4,096 blocks, 2.2x the time it took
 // to write them.  `slices` workgroups may share a block (measured: no better than one).
 #include "hsw_expand.hpp"
+#include "hsw_frame.hpp"
 #include "hsw_verify.h"
 
 namespace hsw {
@@ -31,13 +32,61 @@ DEV bool narrow(const Cell &c) { return (c.l[1] | c.l[2] | c.l[3]) == 0; }
 DEV bool same(const Cell &a, const Cell &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
 DEV Cell small(u64 v) { Cell c; c.l[0] = v; c.l[1] = c.l[2] = c.l[3] = 0; return c; }
 
+// FlexGate column packing: where stream cell i sits
+template <class P>
+DEV u64 place(const P &p, u64 i) {
+    u64 gap = 0;
+    for (u32 k = 0; k < p.n_breaks; k++) gap += p.break_cell[k] <= i ? p.break_gap[k] : 0;
+    return i + gap;
+}
+
+// ---- generic field arithmetic for the few full-width rows of a digest frame (is_zero's z + a*inv = 1, the
+// differences of is_equal / select): canonical 4 x u64 limbs, double-and-add -- slow and simple; a frame has
+// a few hundred such rows, a block none beyond the negation pattern handled inline.
+DEV bool geq_p(const Cell &a) {
+    const u64 P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    for (int i = 3; i >= 0; i--) { if (a.l[i] > P[i]) return true; if (a.l[i] < P[i]) return false; }
+    return true;
+}
+DEV Cell sub_p(const Cell &a) {
+    const u64 P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    Cell r; u64 br = 0;
+    for (int i = 0; i < 4; i++) { const unsigned __int128 d = (unsigned __int128)a.l[i] - P[i] - br; r.l[i] = (u64)d; br = (u64)(d >> 64) & 1; }
+    return r;
+}
+DEV Cell add_mod(const Cell &a, const Cell &b) {          // a, b < p < 2^254: no carry out of 256 bits
+    Cell r; u64 cy = 0;
+    for (int i = 0; i < 4; i++) { const unsigned __int128 s = (unsigned __int128)a.l[i] + b.l[i] + cy; r.l[i] = (u64)s; cy = (u64)(s >> 64); }
+    return geq_p(r) ? sub_p(r) : r;
+}
+DEV Cell mul_mod(const Cell &a, const Cell &b) {
+    Cell r = small(0);
+    for (int bit = 255; bit >= 0; bit--) {
+        r = add_mod(r, r);
+        if ((b.l[bit >> 6] >> (bit & 63)) & 1) r = add_mod(r, a);
+    }
+    return r;
+}
+// x0 + x1*x2 == x3 (mod p) for canonical cells
+DEV bool row_holds(const Cell x[4]) {
+    if (narrow(x[0]) && narrow(x[1]) && narrow(x[2]) && narrow(x[3])) {
+        const unsigned __int128 s = (unsigned __int128)x[1].l[0] * x[2].l[0] + x[0].l[0];
+        return (u64)(s >> 64) == 0 && (u64)s == x[3].l[0];
+    }
+    if (geq_p(x[0]) || geq_p(x[1]) || geq_p(x[2]) || geq_p(x[3])) return false;     // not canonical
+    return same(add_mod(x[0], mul_mod(x[1], x[2])), x[3]);
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     const u64 blk = blockIdx.x / p.slices;
     const u32 tid = (blockIdx.x % p.slices) * blockDim.x + threadIdx.x, nt = p.slices * blockDim.x;
     const uint4 *gate = reinterpret_cast<const uint4 *>(p.gate);
-    const u64 g0 = blk * (u64)p.gate_cells;
+    const u64 dg = p.frame_every ? blk / p.frame_every : 0;
+    const u64 g0 = p.gate_cell0 + blk * (u64)p.gate_cells + dg * p.frame_cells;
+    const bool packed = p.n_breaks != 0;
+    auto gcell = [&](u64 idx) -> Cell { return load_cell(gate, packed ? place(p, idx) : idx); };
     const uint8_t *bytes = p.blocks + 64 * blk;
     const u32 *pre = p.pre_states + 8 * blk;
     u32 bad = 0;
@@ -46,7 +95,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     // a cell by structure id: stream cell or one of the cells outside the block's stream
     auto cell_of = [&](int64_t id, bool &known) -> Cell {
         known = true;
-        if (id >= 0) return load_cell(gate, g0 + (u64)id);
+        if (id >= 0) return gcell(g0 + (u64)id);
         if (id >= -64) return small(bytes[-1 - id]);                        // input byte k = -1 - id
         if (id <= -100 && id >= -107) return small(pre[-100 - id]);          // pre-state word
         if (id == -1000) return small(0);                                    // the Context's zero cell
@@ -64,7 +113,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         const u32 c = p.gate_rows[r];
         Cell x[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = load_cell(gate, g0 + c + j);
+        for (int j = 0; j < 4; j++) x[j] = gcell(g0 + c + j);
         bool ok;
         if (narrow(x[0]) && narrow(x[1]) && narrow(x[2]) && narrow(x[3])) {
             const unsigned __int128 s = (unsigned __int128)x[1].l[0] * x[2].l[0] + x[0].l[0];
@@ -118,7 +167,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         for (u32 j = tid; j < p.lookup_cells; j += nt) {
             bool known;
             const Cell src = cell_of(p.lookup_src[j], known);
-            const Cell v = load_cell(lk, blk * (u64)p.lookup_cells + j);
+            const Cell v = load_cell(lk, p.lookup_cell0 + blk * (u64)p.lookup_cells + dg * p.frame_lookups + j);
             if (!(narrow(v) && v.l[0] < 65536 && (!known || same(v, src)))) fail(VERIFY_LOOKUP, j);
         }
     }
@@ -135,6 +184,100 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
         if (key < old) p.report->first_class = first_class;      // best effort: the class of (one of) the earliest failures
     }
+}
+
+// ---------------------------------------------------------------- digest frames
+// One workgroup per digest: prologue and epilogue cells against their structure, plus the links a
+// replayer would make by copy constraints and this check makes through the arrays both sides were checked
+// against: input length / rounds, the initial state, the input bytes, pre-state of block b = next state of
+// block b - 1, the candidate states of the epilogue.
+__global__ __launch_bounds__(256) void hsw_verify_frame_kernel(FrameVerifyParams p) {
+    const FrameDesc d = p.descs[blockIdx.x];
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const uint4 *gate = reinterpret_cast<const uint4 *>(p.gate);
+    const uint4 *lk = reinterpret_cast<const uint4 *>(p.lookup);
+    const bool packed = p.n_breaks != 0;
+    auto gcell = [&](u64 idx) -> Cell { return load_cell(gate, packed ? place(p, idx) : idx); };
+    u32 bad = 0, first = 0xffffffffu, first_class = 0;
+    auto fail = [&](u32 cls, u32 at) { bad++; if (at < first) { first = at; first_class = cls; } };
+    const u32 N = d.n_blocks;
+    const u32 target = d.num_round - d.precomputed_round;
+    auto state_word = [&](u32 n, u32 i) -> u64 {
+        return n == 0 ? p.pre_states[8 * d.first_block + i] : p.next_states[8 * (d.first_block + n - 1) + i];
+    };
+
+    for (int sec = 0; sec < 2; sec++) {
+        const FrameVerifyParams::Section &S = sec ? p.epi : p.pro;
+        const u64 base = sec ? d.epilogue_cell : d.prologue_cell;
+        const u64 lbase = sec ? d.epilogue_lookup : d.prologue_lookup;
+        const u32 tag = sec ? 0x40000000u : 0u;            // reported cell: section-relative, epilogue flagged
+        // a cell by structure id (section-relative, or a cell of another section)
+        auto cell_of = [&](int64_t id) -> Cell {
+            if (id >= 0) return gcell(base + (u64)id);
+            if (id == FS_ZERO) return small(0);
+            if (id == FS_TARGET) return gcell(d.prologue_cell + frame::P_TGT);
+            const u32 q = (u32)(FS_STATE0 - id);                       // 8 n + i
+            return q < 8 ? gcell(d.prologue_cell + frame::P_STATE + q) : small(state_word(q / 8, q % 8));
+        };
+        for (u32 r = tid; r < S.n_rows; r += nt) {
+            const u32 c = S.gate_rows[r];
+            Cell x[4];
+            for (int j = 0; j < 4; j++) x[j] = gcell(base + c + j);
+            if (!row_holds(x)) fail(VERIFY_GATE_ROW, tag | c);
+        }
+        for (u32 c = tid; c < S.cells; c += nt) {
+            const uint8_t k = S.kind[c];
+            if (k == 0) continue;
+            const Cell v = gcell(base + c);
+            if (k == 1) {
+                const int64_t kv = S.ref[c];
+                Cell want = small((u64)(kv >= 0 ? kv : -kv));
+                if (kv < 0) {                                                       // p - |k|, |k| < 2^62: only limb 0 borrows
+                    want.l[0] = 0x43e1f593f0000001ull - want.l[0];
+                    want.l[1] = 0x2833e84879b97091ull; want.l[2] = 0xb85045b68181585dull; want.l[3] = 0x30644e72e131a029ull;
+                }
+                if (!same(v, want)) fail(VERIFY_CONSTANT, tag | c);
+            } else if (!same(v, cell_of(S.ref[c]))) fail(VERIFY_COPY, tag | c);
+        }
+        for (u32 i = tid; i < S.n_assert_eq; i += nt)
+            if (!same(cell_of(S.assert_eq[2 * i]), cell_of(S.assert_eq[2 * i + 1]))) fail(VERIFY_ASSERT_EQ, tag | (u32)S.assert_eq[2 * i + 1]);
+        for (u32 i = tid; i < S.n_assert_const; i += nt)
+            if (!same(cell_of(S.assert_const[2 * i]), small((u64)S.assert_const[2 * i + 1]))) fail(VERIFY_CONSTANT, tag | (u32)S.assert_const[2 * i]);
+        for (u32 i = tid; i < S.n_range; i += nt) {
+            const Cell v = cell_of(S.range[2 * i]);
+            if (!(narrow(v) && (v.l[0] >> S.range[2 * i + 1]) == 0)) fail(VERIFY_RANGE, tag | (u32)S.range[2 * i]);
+        }
+        if (lk)
+            for (u32 j = tid; j < S.n_lookup; j += nt) {
+                const Cell v = load_cell(lk, lbase + j);
+                if (!(narrow(v) && v.l[0] < 65536 && same(v, cell_of(S.lookup_src[j])))) fail(VERIFY_LOOKUP, tag | j);
+            }
+    }
+    // ---- the facts of this digest and the links between the sections ----
+    const u64 P0 = d.prologue_cell;
+    if (tid == 0) {
+        if (!same(gcell(P0 + frame::P_LEN), small(d.input_len))) fail(VERIFY_COPY, frame::P_LEN);           // AssignedHashResult.input_len
+        if (!same(gcell(P0 + frame::P_PRE), small(d.precomputed_round))) fail(VERIFY_COPY, frame::P_PRE);
+        if (d.zero_cell != ~0ull && !same(gcell(d.zero_cell), small(0))) fail(VERIFY_CONSTANT, frame::P_BYTES - 1);
+        (void)target;
+    }
+    if (tid < 8 && !same(gcell(P0 + frame::P_STATE + tid), small(state_word(0, tid)))) fail(VERIFY_COPY, frame::P_STATE + tid);
+    for (u32 i = tid; i < 64u * N; i += nt)                                                                  // input bytes
+        if (!same(gcell(P0 + frame::P_BYTES + i), small(p.blocks[64 * d.first_block + i]))) fail(VERIFY_COPY, frame::P_BYTES + i);
+    for (u32 i = tid; i < 8u * (N - 1); i += nt)                                                             // the chain
+        if (p.pre_states[8 * (d.first_block + 1) + i] != p.next_states[8 * d.first_block + i]) fail(VERIFY_NEXT_STATE, i);
+    if (bad) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&p.report->violations), (unsigned long long)bad);
+        const unsigned long long key = ((unsigned long long)d.first_block << 32) | first;
+        const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
+        if (key < old) p.report->first_class = first_class;
+    }
+}
+
+hipError_t launch_verify_frames(const FrameVerifyParams &p, size_t n_digests, hipStream_t stream) {
+    if (n_digests == 0) return hipSuccess;
+    hipLaunchKernelGGL(hsw_verify_frame_kernel, dim3((unsigned)n_digests), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream) {

@@ -145,6 +145,14 @@ class Sha256DynamicConfig:
             out["lookup"] = lookup[: int(v.lookup_cells)]
         return out
 
+    def verify(self):
+        """hsw_gadget_verify: everything written so far against the constraint system, on the device."""
+        rep = N.VerifyReport()
+        self._ok(self.lib.hsw_gadget_verify(self.h, C.byref(rep)))
+        return dict(violations=int(rep.violations), checks=int(rep.checks), first_block=int(rep.first_block),
+                    first_cell=int(rep.first_cell), first_class=N.VerifyReport.CLASSES.get(int(rep.first_class)),
+                    kernel_ms=float(rep.kernel_ms))
+
     def seek(self, hash_idx):
         """Continue at digest #hash_idx as if the earlier ones had been assigned (their positions
         follow from max_variable_byte_sizes alone): lets several GPUs share one circuit's digests."""

@@ -236,8 +236,8 @@ int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, ui
  * spread table), lookup-column copy and next-state word, with the block bytes and pre-states entering
  * only through the cells they are copy-constrained to.  No value is recomputed from the inputs, so a
  * stream that passes IS the witness of its inputs (every cell is forced by those constraints).  Takes
- * the buffers of a hsw_witness_blocks(_ex) call (canonical cells, plain linear stream: no pack / frames;
- * chip, lookup and next-state pointers may be NULL = not checked).  Synchronous. */
+ * the buffers and layout of a hsw_witness_blocks(_ex) call (canonical cells; pack and frame_* as given
+ * there; chip, lookup and next-state pointers may be NULL = not checked).  Synchronous. */
 #define HSW_VERIFY_CONSTANT   1u
 #define HSW_VERIFY_COPY       2u
 #define HSW_VERIFY_GATE_ROW   3u
@@ -256,6 +256,17 @@ typedef struct hsw_verify_report {
 } hsw_verify_report;
 struct hsw_witness_args;
 int hsw_verify_blocks(hsw_engine *e, const struct hsw_witness_args *args, hsw_verify_report *report);
+struct hsw_frame_desc;
+struct hsw_pack_plan;
+/* The same for the digest frames hsw_witness_frames wrote (one call = equally shaped digests: same
+ * n_blocks and range-check setting): prologue and epilogue cells against hsw_frame_structure -- full
+ * field arithmetic for the rows with full-width cells -- plus the facts and links of each digest (input
+ * length, precomputed rounds, initial state, input bytes, pre-state of block b = next state of block
+ * b - 1, the epilogue's candidate states).  first_cell: section-relative, bit 30 set for the epilogue. */
+int hsw_verify_frames(hsw_engine *e, const struct hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                      const uint32_t *d_pre_states, const uint32_t *d_next_states, const void *d_gate,
+                      const void *d_lookup, const struct hsw_pack_plan *pack, uint32_t flags,
+                      hsw_verify_report *report);
 
 typedef struct hsw_witness_args {
     const uint8_t *d_blocks;       /* as hsw_witness_blocks */
@@ -482,6 +493,10 @@ int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst);
  * configuration): rank r seeks to its first digest and assigns its share into the same positions
  * the serial reference would use; no exchange is needed to agree on the layout. */
 int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx);
+/* Check everything the gadget has written so far against the constraint system, on the device:
+ * hsw_verify_blocks on every run of blocks + hsw_verify_frames on their frames (whole-digest contexts;
+ * linear stream or column image), or hsw_verify_blocks alone (block-stream contexts).  Canonical cells. */
+int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report);
 /* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);
 /* Sha256DynamicConfig::digest (lib.rs:71-349); precomputed_input_len 0 = None.

@@ -277,6 +277,11 @@ extern "C" {
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
+    pub fn hsw_verify_frames(e: *mut hsw_engine, descs: *const hsw_frame_desc, n: usize, d_blocks: *const u8,
+                             d_pre_states: *const u32, d_next_states: *const u32, d_gate: *const c_void,
+                             d_lookup: *const c_void, pack: *const hsw_pack_plan, flags: u32,
+                             report: *mut hsw_verify_report) -> c_int;
+    pub fn hsw_gadget_verify(g: *mut hsw_gadget, report: *mut hsw_verify_report) -> c_int;
     pub fn hsw_verify_blocks(e: *mut hsw_engine, args: *const hsw_witness_args, report: *mut hsw_verify_report) -> c_int;
     pub fn hsw_frame_structure(shape: *const hsw_shape, max_variable_byte_size: usize, is_input_range_check: c_int,
                                section: c_int, counts: *mut hsw_frame_structure_counts, cell_kind: *mut u8,

@@ -113,8 +113,8 @@ def test_verify_rejects_what_it_cannot_check(engine_factory, hsw):
     a.flags = N.HSW_REPR_MONTGOMERY
     assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_UNSUPPORTED
     a.flags = 0
-    a.frame_every = 1
-    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_UNSUPPORTED
+    a.frame_every = 1                             # digest frames exist in internals mode only
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
     a.frame_every = 0
     a.d_lookup = out["gate"].data_ptr()
     assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
@@ -132,3 +132,70 @@ def test_verify_full_batch(engine_factory):
     out["gate"][4000 * eng.G + 12345, 0] ^= 1
     rep = eng.verify_blocks(tb, tp, out)
     assert rep["violations"] >= 1 and rep["first_block"] == 4000 and rep["first_cell"] in (12345, 12344, 12343, 12342)
+
+
+@pytest.fixture(scope="module")
+def eng_int(hsw):
+    e = hsw.WitnessEngine(0, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("columns", [None, 100003])
+def test_gadget_verify_whole_regions(hsw, eng_int, columns):
+    """hsw_gadget_verify on whole-digest contexts: blocks + frames (full field arithmetic for the rows with
+    full-width cells) + the links between prologue, blocks and epilogue; linear streams and column images."""
+    sizes = [128, 128, 64, 192]
+    msgs = [b"abc", b"", b"x" * 40, bytes(range(150))]
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+    if columns:
+        cfg.set_columns(columns)
+    res = cfg.digest_batch(msgs[:3], [None] * 3) + [cfg.digest(msgs[3])]
+    rep = cfg.verify()
+    assert rep["violations"] == 0 and rep["checks"] > 8 * 80000
+    v = cfg.view()
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def poke(cell, delta=1):
+        """add delta to limb 0 of stream cell `cell`, in place in the gadget's HBM buffer"""
+        col, row = cfg.cell_position(cell)
+        at = (col * int(v.max_rows) + row) if columns else cell
+        buf = np.zeros(4, dtype=np.uint64)
+        cfg._ok(cfg.lib.hsw_download(eng_int.h, buf.ctypes.data, v.d_gate + at * 32, 32))
+        buf[0] = np.uint64((int(buf[0]) + delta) % (1 << 64))
+        assert hip.hipMemcpy(C.c_void_p(v.d_gate + at * 32), C.c_void_p(buf.ctypes.data), 32, 1) == 0   # host -> device
+
+    r1 = res[1]
+    probes = [
+        (r1.prologue_cell + 0, "copy"),                     # input_len
+        (r1.prologue_cell + 18, None),                      # the -2^16 constant
+        (r1.prologue_cell + 27, "free"),                    # inverse witness of is_zero(0): unconstrained
+        (r1.prologue_cell + 46 + 5, None),                  # an input byte
+        (r1.block_cell + 12345, None),                      # inside a block
+        (r1.epilogue_cell + 6, None),                       # (n - target)^-1 of candidate 0
+        (r1.epilogue_cell + 12 + 7, None),                  # a select output
+        (r1.end_cell - 1, None),                            # last cell of the digest's recomposition
+    ]
+    for cell, want in probes:
+        poke(cell, 1)
+        rep = cfg.verify()
+        if want == "free":
+            assert rep["violations"] == 0, cell
+        else:
+            assert rep["violations"] >= 1, cell
+        poke(cell, -1)
+        assert cfg.verify()["violations"] == 0, cell
+    cfg.close()
+
+
+def test_gadget_verify_block_stream_contexts(engine_factory, hsw):
+    eng = engine_factory(8, 2)
+    cfg = hsw.Sha256DynamicConfig(eng, [1024, 64, 4096], True)
+    cfg.digest(bytes(range(200)) * 4)            # 16 blocks: inputs read in place from pinned memory
+    cfg.digest(b"q")                              # 1 block
+    cfg.digest(b"long " * 700)                    # 64 blocks: copied
+    rep = cfg.verify()
+    assert rep["violations"] == 0 and rep["checks"] > 81 * 70000
+    cfg.close()
