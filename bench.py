@@ -389,7 +389,11 @@ def main():
                 rw = cfgw.digest(m56)
                 assert eng_i.lib.hsw_gadget_download_region(cfgw.h, C.byref(dst)) == 0
                 tdl.append(time.perf_counter() - t1)
+            vrep = cfgw.verify()
             vw = cfgw.view()
+            extra["config0_bench_circuit_whole_region_verify"] = {
+                "violations": vrep["violations"], "checks": vrep["checks"], "kernel_ms": vrep["kernel_ms"],
+                "note": "hsw_gadget_verify: blocks + frames + links of the whole region, column image, on the device"}
             extra["config0_bench_circuit_whole_region_to_host"] = {
                 "ms_per_synthesis": float(np.median(tdl)) * 1e3, "bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
                 "note": "synthesis + D2H of the used rows of the 9 gate columns and the lookup column into pinned memory (PCIe-bound); the chip columns would add 2 x 2 x 32,960 cells"}

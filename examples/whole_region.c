@@ -41,6 +41,14 @@ int main(void) {
            (unsigned long long)v.max_rows, (unsigned long long)v.gate_cells, (unsigned long long)v.lookup_cells);
     if (columns != 9 || v.gate_cells != 1116315 || v.lookup_cells != 53059) return 1;
 
+    /* the library's own MockProver-style check of the whole region, on the device */
+    hsw_verify_report rep;
+    rc = hsw_gadget_verify(g, &rep);
+    if (rc != HSW_OK) die("hsw_gadget_verify", rc, eng);
+    printf("verified on the device: %llu constraints, %llu violations\n", (unsigned long long)rep.checks,
+           (unsigned long long)rep.violations);
+    if (rep.violations != 0) return 1;
+
     /* AssignedHashResult.output_bytes: the 32 load_witness cells of the epilogue (lib.rs:317-324) */
     char hex[65];
     for (int w = 0; w < 8; w++) {

@@ -59,7 +59,32 @@ DEV Cell add_mod(const Cell &a, const Cell &b) {          // a, b < p < 2^254: n
     for (int i = 0; i < 4; i++) { const unsigned __int128 s = (unsigned __int128)a.l[i] + b.l[i] + cy; r.l[i] = (u64)s; cy = (u64)(s >> 64); }
     return geq_p(r) ? sub_p(r) : r;
 }
+DEV Cell neg_mod(const Cell &a) {                           // p - a (0 stays 0)
+    if ((a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0) return a;
+    const u64 P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    Cell r; u64 br = 0;
+    for (int i = 0; i < 4; i++) { const unsigned __int128 d = (unsigned __int128)P[i] - a.l[i] - br; r.l[i] = (u64)d; br = (u64)(d >> 64) & 1; }
+    return r;
+}
+// a * k for a 64-bit k: double-and-add from k's top bit
+DEV Cell mul_small(const Cell &a, u64 k) {
+    Cell r = small(0);
+    if (k == 0) return r;
+    for (int bit = 63 - __builtin_clzll(k); bit >= 0; bit--) {
+        r = add_mod(r, r);
+        if ((k >> bit) & 1) r = add_mod(r, a);
+    }
+    return r;
+}
+// a * b: through the operand that is small, or the negation of something small (the differences n - target,
+// state_n - state_target, -2^16 of a frame are); both full width only for corrupted cells
 DEV Cell mul_mod(const Cell &a, const Cell &b) {
+    if (narrow(b)) return mul_small(a, b.l[0]);
+    if (narrow(a)) return mul_small(b, a.l[0]);
+    const Cell nb = neg_mod(b);
+    if (narrow(nb)) return neg_mod(mul_small(a, nb.l[0]));
+    const Cell na = neg_mod(a);
+    if (narrow(na)) return neg_mod(mul_small(b, na.l[0]));
     Cell r = small(0);
     for (int bit = 255; bit >= 0; bit--) {
         r = add_mod(r, r);

@@ -53,3 +53,4 @@ def test_whole_region_example_runs_the_bench_circuit(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "advice columns: 9 x 131063 rows; gate cells 1116315, lookup cells 53059" in r.stdout
     assert hashlib.sha256(bytes([1] * 56)).hexdigest() in r.stdout and r.stdout.strip().endswith("ok")
+    assert " constraints, 0 violations" in r.stdout
