@@ -186,11 +186,11 @@ struct Em {
     static constexpr bool MONT = REPR_ == 1;
     static constexpr bool COMPACT = REPR_ == 2;
     static constexpr bool RC = RC_;   // halo2-base internals: range_check cells + lookup-column stream (A3)
-    static constexpr int STRIDE = T + 3;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
     // Realigned write-out (flush_tile).  Free for the HBM-bound canonical kernels; the Montgomery kernels
     // are issue-bound and pay ~4 % for it even on aligned streams, so they realign only in internals mode,
     // where misaligned streams are the rule (digest frames, column images); compact cells never do.
     static constexpr bool REALIGN = REPR_ == 0 || (REPR_ == 1 && RC_);
+    static constexpr int STRIDE = REALIGN ? T + 3 : T + 1;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
     u64 *row0;         // this lane's tile row (LDS), column 0
     u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
     u32 carry_neg;     // bit j: carried column j holds a field negation
@@ -870,16 +870,17 @@ DEV bool phase_window(bool split, int phase, u32 part, u32 parts, u32 &wpart, u3
 template <int L, int T, int R, int REPR, bool RC>
 __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     using LY = Lay<L, RC>;
-    static_assert(R * (T + 3) * 8 >= 800, "tile must be able to hold the chain seeds");
+    using EM = Em<T, R, REPR, RC>;
+    static_assert(R * EM::STRIDE * 8 >= 800, "tile must be able to hold the chain seeds");
     // The chain seeds live in LDS only until every lane has pulled its own into
     // registers; the tile then reuses the same bytes (keeps the workgroup at
     // <= 20 KiB of LDS = 8 waves per CU, so 4,096 blocks are exactly 2 waves of
     // residency on 256 CUs).
-    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * (T + 3)];   // +1 scratch row for lanes >= R; +3 carry columns
+    __shared__ u64 s_tile[(R + (R < 64 ? 1 : 0)) * EM::STRIDE];   // +1 scratch row for lanes >= R
     u32 *sW = reinterpret_cast<u32 *>(s_tile);   // [64]
     u32 *sA = sW + 64;         // [68] sA[k] = a-value A[k-3]: A[-3..0] = d,c,b,a of the pre-state
     u32 *sE = sA + 68;         // [68] sE[k] = e-value E[k-3]: E[-3..0] = h,g,f,e of the pre-state
-    __shared__ u64 s_head[R * 3];                 // realignment: held-back first cells of every unit (flush_tile)
+    __shared__ u64 s_head[EM::REALIGN ? R * 3 : 1];   // realignment: held-back first cells of every unit (flush_tile)
     __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
     __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
 
@@ -948,11 +949,10 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
     __syncthreads();           // seeds are in registers: the tile may now overwrite them
 
-    using EM = Em<T, R, REPR, RC>;
     EM em;
     em.lk16 = s_lk16;
     em.tile = s_tile;
-    em.row0 = s_tile + (lane < (u32)R ? lane : (u32)R) * (T + 3);   // lanes >= R never flush: scratch row
+    em.row0 = s_tile + (lane < (u32)R ? lane : (u32)R) * EM::STRIDE;   // lanes >= R never flush: scratch row
     em.row = em.row0;
     em.skew = 0;
     em.carry_neg = 0;
