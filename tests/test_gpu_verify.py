@@ -199,3 +199,36 @@ def test_gadget_verify_block_stream_contexts(engine_factory, hsw):
     rep = cfg.verify()
     assert rep["violations"] == 0 and rep["checks"] > 81 * 70000
     cfg.close()
+
+
+def test_verify_shard_of_configs3_and_beyond(engine_factory):
+    """BASELINE configs[3]'s per-GPU shard is 8,192 blocks (19.5 GB); twice that (39 GB, byte offsets far
+    past 2^32 and cell indices past 2^30) generated at an odd cursor and checked in HBM by the product's
+    own verifier -- no host copy of the streams is ever made."""
+    import hashlib
+    import torch
+    eng = engine_factory(8, 2)
+    n = 16384
+    rng = np.random.default_rng(0xC4)
+    msgs = rng.integers(0, 256, (n, 55), dtype=np.uint8)
+    blocks = np.zeros((n, 64), dtype=np.uint8)
+    blocks[:, :55] = msgs
+    blocks[:, 55] = 0x80
+    blocks[:, 62], blocks[:, 63] = (55 * 8) >> 8, (55 * 8) & 0xFF
+    iv = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
+    tb = torch.from_numpy(blocks).cuda()
+    tp = torch.from_numpy(np.tile(iv, (n, 1)).view(np.int32)).cuda()
+    cursor0 = 3 * 4120 + 1                       # odd: first / last chip rows are shared with neighbours
+    out = eng.witness_blocks(tb, tp, cursor0=cursor0)
+    eng.synchronize()
+    rep = eng.verify_blocks(tb, tp, out, cursor0=cursor0)
+    assert rep["violations"] == 0 and rep["checks"] > 1.2e9
+    ns = out["next_states"].cpu().numpy().view(np.uint32)
+    for i in (0, 1, 8191, 8192, n - 1):
+        assert b"".join(int(x).to_bytes(4, "big") for x in ns[i]) == hashlib.sha256(msgs[i].tobytes()).digest()
+    # a corruption in the very last block is found, at the right place
+    out["gate"][(n - 1) * eng.G + 66000, 0] ^= 1
+    rep = eng.verify_blocks(tb, tp, out, cursor0=cursor0)
+    assert rep["violations"] >= 1 and rep["first_block"] == n - 1
+    del out
+    torch.cuda.empty_cache()
