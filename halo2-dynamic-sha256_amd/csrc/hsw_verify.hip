@@ -8,9 +8,11 @@
 // copy-constrained to.  The structure is the product's own (csrc/hsw_structure.hpp); no value is
 // recomputed from the inputs, so a stream that passes is the witness of its inputs by the uniqueness
 // argument of SURVEY 8c.  Canonical 32-byte cells.  One pass over the gate rows checks the row equation and,
-// on the same four loads, the constants and copies among the row's cells; the scattered 32-byte loads of
-// copy sources (a 128-byte line each) are what bounds it: ~3.8 ms for 4,096 blocks, 2.2x the time it took
-// to write them.  `slices` workgroups may share a block (measured: no better than one).
+// on the same four loads, the constants and copies among the row's cells.  ~3.8 ms for 4,096 blocks (2.2x
+// the time it took to write them): latency-bound on the chain structure -> cell -> copy source, not on
+// bytes -- staging the stream through LDS in 1,024-cell windows made no difference (94 % of the copy
+// sources are within 1,024 cells of their copy).  `slices` workgroups may share a block: small batches
+// are sliced to fill the chip.
 #include "hsw_expand.hpp"
 #include "hsw_frame.hpp"
 #include "hsw_verify.h"
