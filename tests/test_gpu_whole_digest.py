@@ -366,3 +366,24 @@ def test_download_region_to_host(hsw, oracle, eng_int, columns):
     assert np.array_equal(h["gate"], d["gate"]) and np.array_equal(h["dense"], d["dense"]) and "lookup" not in h
     plain.close()
     eng.close()
+
+
+def test_whole_region_montgomery_column_image(hsw, oracle, eng_int):
+    """What a Rust shim would take: the column image in Montgomery form (halo2curves' in-memory Fr) --
+    TestCircuit shape, 3 columns -- equals the oracle's canonical cells times 2^256 mod p, gaps zero."""
+    N = hsw._native
+    msgs, sizes = [b"abc", b""], [128, 128]
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+    cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    assert cfg.set_columns((1 << 17) - 9) == 3
+    res = cfg.digest_batch(msgs, [None, None])
+    st = cfg.streams()
+    host = cfg.download_region()
+    cfg.close()
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    img, _ = _model_columns(ref["call_lens"], oracle.to_montgomery(ref["gate"]), (1 << 17) - 9)
+    assert np.array_equal(st["gate"], img) and np.array_equal(host["gate"], img)
+    assert np.array_equal(st["lookup"], oracle.to_montgomery(ref["lookup"]))
+    assert np.array_equal(st["dense"], oracle.to_montgomery(ref["dense"])[:, : st["rows"]])
+    for m, r in zip(msgs, res):
+        assert r.output_bytes == hashlib.sha256(m).digest()
