@@ -635,7 +635,7 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     std::memset(report, 0, sizeof *report);
     if (args->n_blocks == 0) return HSW_OK;
     if (!args->d_gate || !args->d_blocks || !args->d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
-    if (args->flags & HSW_REPR_MASK) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks canonical cells");
+    if (args->flags & HSW_REPR_COMPACT64) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_blocks checks 32-byte cells (canonical or Montgomery)");
     if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
     if (args->frame_every && e->mode != HSW_MODE_HALO2_INTERNALS)
         return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
@@ -650,6 +650,7 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     p.blocks = args->d_blocks; p.pre_states = args->d_pre_states; p.next_states = args->d_next_states;
     p.cursor0 = args->spread_cursor0; p.chip_col_stride = args->chip_col_stride;
     p.ncols = e->shape.num_advice_columns; p.num_bits_lookup = e->shape.num_bits_lookup;
+    p.montgomery = (args->flags & HSW_REPR_MONTGOMERY) ? 1u : 0u;
     p.gate_cell0 = p.lookup_cell0 = 0;
     p.frame_every = args->frame_every; p.frame_cells = args->frame_cells; p.frame_lookups = args->frame_lookups;
     p.n_breaks = args->pack ? args->pack->n_breaks : 0;
@@ -693,7 +694,7 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
     if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
     if (e->mode != HSW_MODE_HALO2_INTERNALS)
         return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
-    if (flags & HSW_REPR_MASK) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_frames checks canonical cells");
+    if (flags & HSW_REPR_COMPACT64) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_frames checks 32-byte cells (canonical or Montgomery)");
     if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
     for (size_t i = 0; i < n; i++) {
         if (descs[i].n_blocks == 0 || descs[i].n_blocks != descs[0].n_blocks ||
@@ -741,6 +742,7 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
     p.descs = reinterpret_cast<const hsw::FrameDesc *>(dbuf + o_desc);
     p.gate = d_gate; p.lookup = d_lookup; p.blocks = d_blocks; p.pre_states = d_pre_states; p.next_states = d_next_states;
     p.n_breaks = pack ? pack->n_breaks : 0;
+    p.montgomery = (flags & HSW_REPR_MONTGOMERY) ? 1u : 0u;
     for (uint32_t k = 0; k < p.n_breaks; k++) { p.break_cell[k] = pack->break_cell[k]; p.break_gap[k] = pack->break_gap[k]; }
     uint64_t checks = 0;
     for (int s2 = 0; s2 < 2; s2++) {

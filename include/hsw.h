@@ -236,7 +236,8 @@ int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, ui
  * spread table), lookup-column copy and next-state word, with the block bytes and pre-states entering
  * only through the cells they are copy-constrained to.  No value is recomputed from the inputs, so a
  * stream that passes IS the witness of its inputs (every cell is forced by those constraints).  Takes
- * the buffers and layout of a hsw_witness_blocks(_ex) call (canonical cells; pack and frame_* as given
+ * the buffers and layout of a hsw_witness_blocks(_ex) call (canonical or Montgomery cells -- the latter
+ * are reduced on load; pack and frame_* as given
  * there; chip, lookup and next-state pointers may be NULL = not checked).  Synchronous. */
 #define HSW_VERIFY_CONSTANT   1u
 #define HSW_VERIFY_COPY       2u
@@ -495,7 +496,8 @@ int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst);
 int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx);
 /* Check everything the gadget has written so far against the constraint system, on the device:
  * hsw_verify_blocks on every run of blocks + hsw_verify_frames on their frames (whole-digest contexts;
- * linear stream or column image), or hsw_verify_blocks alone (block-stream contexts).  Canonical cells. */
+ * linear stream or column image), or hsw_verify_blocks alone (block-stream contexts).  Canonical or
+ * Montgomery cells. */
 int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report);
 /* (column, row) of gate-stream cell `cell` (identity on row without set_columns). */
 int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row);

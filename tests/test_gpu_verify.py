@@ -110,7 +110,7 @@ def test_verify_rejects_what_it_cannot_check(engine_factory, hsw):
     a = N.WitnessArgs()
     a.d_blocks, a.d_pre_states, a.n_blocks, a.d_gate = tb.data_ptr(), tp.data_ptr(), 1, out["gate"].data_ptr()
     rep = N.VerifyReport()
-    a.flags = N.HSW_REPR_MONTGOMERY
+    a.flags = N.HSW_REPR_COMPACT64                # 8-byte cells cannot hold the negations
     assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_UNSUPPORTED
     a.flags = 0
     a.frame_every = 1                             # digest frames exist in internals mode only
@@ -232,3 +232,35 @@ def test_verify_shard_of_configs3_and_beyond(engine_factory):
     assert rep["violations"] >= 1 and rep["first_block"] == n - 1
     del out
     torch.cuda.empty_cache()
+
+
+def test_verify_montgomery_streams(engine_factory, hsw, eng_int):
+    """Montgomery cells are reduced on load and checked in the canonical domain: block streams and whole
+    regions (column image), and a flipped cell is still found."""
+    import ctypes as C
+    import torch
+    N = hsw._native
+    eng = engine_factory(8, 2)
+    blocks, pre = _inputs(5, 21)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    out = eng.witness_blocks(tb, tp, cursor0=6, flags=N.HSW_REPR_MONTGOMERY)
+    eng.synchronize()
+    a = N.WitnessArgs()
+    a.d_blocks, a.d_pre_states, a.n_blocks, a.spread_cursor0 = tb.data_ptr(), tp.data_ptr(), 5, 6
+    a.d_gate, a.d_chip_dense, a.d_chip_spread = out["gate"].data_ptr(), out["dense"].data_ptr(), out["spread"].data_ptr()
+    a.chip_col_stride, a.d_next_states, a.flags = out["dense"].shape[1], out["next_states"].data_ptr(), N.HSW_REPR_MONTGOMERY
+    rep = N.VerifyReport()
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations == 0
+    a.flags = 0                                   # the same bytes read as canonical cells are garbage
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations > 100000
+    a.flags = N.HSW_REPR_MONTGOMERY
+    out["gate"][3 * eng.G + 777, 2] ^= 1 << 40
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations >= 1 and rep.first_block == 3
+    # whole region, Montgomery, column image
+    cfg = hsw.Sha256DynamicConfig(eng_int, [128, 128], is_input_range_check=True, whole_digest=True)
+    cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    cfg.set_columns((1 << 17) - 9)
+    cfg.digest_batch([b"abc", b""], [None, None])
+    rep2 = cfg.verify()
+    assert rep2["violations"] == 0 and rep2["checks"] > 4 * 80000
+    cfg.close()
