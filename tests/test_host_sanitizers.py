@@ -22,7 +22,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
     san = ["-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer"]
     objs = []
-    for src in (os.path.join(CSRC, "hsw_api.cpp"), os.path.join(CSRC, "hsw_gadget.cpp"),
+    for src in (os.path.join(CSRC, "hsw_api.cpp"), os.path.join(CSRC, "hsw_api_region.cpp"), os.path.join(CSRC, "hsw_gadget.cpp"),
                 os.path.join(ROOT, "tests", "cpp", "host_sanity.cpp")):
         obj = str(tmp_path / (os.path.basename(src) + ".o"))
         r = subprocess.run([hipcc, "--offload-arch=gfx950"] + san + ["-c", src, "-o", obj],
