@@ -303,6 +303,7 @@ def test_seek_deals_one_circuit_to_two_gadgets(hsw, oracle, eng_int, columns):
         if first:
             cfg.seek(first)
         res = cfg.digest_batch(msgs[first:last], [None] * (last - first))
+        assert cfg.verify()["violations"] == 0            # also right after a seek: only what this gadget wrote
         # the gadget's view only covers what it has written; read the whole buffers
         v = cfg.view()
         n_gate = int(v.max_rows * v.columns) if max_rows else int(v.gate_capacity)
