@@ -1,7 +1,8 @@
 // hsw_expand.hpp -- gfx950 (MI355X / CDNA4) kernels of the SHA-256 witness engine.
 //
 // One 64-lane wavefront per work item (workgroup = one wave); a block is one
-// work item, or is dealt to 2..16 of them (`parts`).
+// work item, or is dealt to 2..32 of them (`parts`): each takes a share of the
+// units of every phase, or -- tiny batches, "split" mode -- the units of one phase.
 //
 //  chain phase   the plain SHA-256 recurrence of the block (W[0..63] and the a/e
 //                value born in every round) is computed once, wave-uniform, and
@@ -13,7 +14,7 @@
 //                (compression.rs:57-96 for a schedule step, :125-196 for a
 //                round) -- and appends each gate cell to its own row of an
 //                [R][T] LDS tile of 64-bit values.  WHERE a cell goes is a
-//                compile-time cursor type (Cur<POS, FLUSHES, NEG0, NEG1>)
+//                compile-time cursor type (Cur<POS, FLUSHES, NEG0..NEG3, CN>)
 //                threaded through every gate function, so an emitted cell is
 //                one ds_write_b64 at an immediate offset and each flush point
 //                is an `if constexpr`.  Spread/dense conversions are shift/mask
@@ -24,6 +25,9 @@
 //                (canonical form).  Montgomery form (x * 2^256 mod p,
 //                halo2curves' in-memory Fr) does one 64x256-bit
 //                multiply + Barrett reduce per cell, one lane per cell.
+//                A stream that does not start on a 128-byte line (digest frames,
+//                column breaks) is realigned: skewed tile columns, carried cells
+//                and held-back unit heads keep every run on whole lines (flush_tile).
 //  chip columns  the 16-bit dense input of every SpreadConfig::spread call is
 //                staged in LDS; at the end of each phase the chip columns
 //                denses[c] / spreads[c] (spread.rs:196-233) receive one
