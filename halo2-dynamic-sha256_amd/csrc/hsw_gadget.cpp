@@ -243,8 +243,14 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
         gate_cells = (size_t)cells;
     }
     hipError_t he = hipMalloc(&c->d_gate, gate_cells * HSW_CELL_BYTES);
-    if (he == hipSuccess && whole_digest)
-        he = hipMalloc(&c->d_lookup, (size_t)(c->lookup_capacity ? c->lookup_capacity : 1) * HSW_CELL_BYTES);
+    // touch the stream buffers once: the first write into fresh device memory is several times slower
+    // (measured: 16-block digests 266 us instead of 54 us while a context's buffer was still untouched)
+    if (he == hipSuccess) he = hipMemset(c->d_gate, 0, gate_cells * HSW_CELL_BYTES);
+    if (he == hipSuccess && whole_digest) {
+        const size_t lbytes = (size_t)(c->lookup_capacity ? c->lookup_capacity : 1) * HSW_CELL_BYTES;
+        he = hipMalloc(&c->d_lookup, lbytes);
+        if (he == hipSuccess) he = hipMemset(c->d_lookup, 0, lbytes);
+    }
     const size_t col_bytes = (size_t)s.num_advice_columns * (c->chip_col_stride ? c->chip_col_stride : 1) * HSW_CELL_BYTES;
     if (he == hipSuccess) he = hipMalloc(&c->d_chip_dense, col_bytes);
     if (he == hipSuccess) he = hipMalloc(&c->d_chip_spread, col_bytes);
