@@ -168,7 +168,7 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     // tools/verify_slices.py); smaller batches are sliced so that ~1,024 workgroups run
     p.slices = e->verify_slices > 0 ? (uint32_t)e->verify_slices
                : (uint32_t)(args->n_blocks >= 1024 ? 1 : (1024 / args->n_blocks > 64 ? 64 : 1024 / args->n_blocks));
-    const hsw::VerifyReport zero{0, ~0ull, 0, 0};
+    const hsw::VerifyReport zero{0, ~0ull, 0};
     hipError_t he = hipMemcpyAsync(e->d_report, &zero, sizeof zero, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) he = hipEventRecord(e->ev0, e->stream);
     if (he == hipSuccess) he = hsw::launch_verify(p, args->n_blocks, e->stream);
@@ -186,9 +186,9 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
     if (args->d_next_states) per_block += 8;
     report->checks = per_block * args->n_blocks;
     if (got.violations) {
-        report->first_block = got.first_key >> 32;
-        report->first_cell = (int64_t)(got.first_key & 0xffffffffu);
-        report->first_class = got.first_class;
+        report->first_block = got.first_key >> 36;
+        report->first_cell = (int64_t)((got.first_key >> 4) & 0xffffffffu);
+        report->first_class = (uint32_t)(got.first_key & 15u);
     }
     return HSW_OK;
 }
@@ -271,7 +271,7 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
     }
     checks += 2 + 8 + 64ull * descs[0].n_blocks + 8ull * (descs[0].n_blocks - 1);      // facts and links
     p.report = e->d_report;
-    const hsw::VerifyReport zero{0, ~0ull, 0, 0};
+    const hsw::VerifyReport zero{0, ~0ull, 0};
     he = hipMemcpyAsync(dbuf, h.data(), h.size(), hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(e->d_report, &zero, sizeof zero, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) he = hipEventRecord(e->ev0, e->stream);
@@ -287,9 +287,9 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
     report->violations = got.violations;
     report->checks = checks * n;
     if (got.violations) {
-        report->first_block = got.first_key >> 32;
-        report->first_cell = (int64_t)(got.first_key & 0xffffffffu);
-        report->first_class = got.first_class;
+        report->first_block = got.first_key >> 36;
+        report->first_cell = (int64_t)((got.first_key >> 4) & 0xffffffffu);
+        report->first_class = (uint32_t)(got.first_key & 15u);
     }
     return HSW_OK;
 }

@@ -17,9 +17,8 @@ enum : int64_t { FS_ZERO = -1000, FS_TARGET = -3000, FS_STATE0 = -4000 };   // F
 
 struct VerifyReport {              // device memory
     uint64_t violations;
-    uint64_t first_key;            // (block << 32) | cell of the earliest failure; ~0 = none
-    uint32_t first_class;
-    uint32_t pad_;
+    uint64_t first_key;            // (block << 36) | (cell << 4) | class of the earliest failure; ~0 = none
+    uint64_t pad_;
 };
 
 struct VerifyParams {

@@ -241,10 +241,9 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     }
     if (bad) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&p.report->violations), (unsigned long long)bad);
-        // first failing (block, cell): smallest packed key wins
-        const unsigned long long key = (blk << 32) | first;
-        const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
-        if (key < old) p.report->first_class = first_class;      // best effort: the class of (one of) the earliest failures
+        // first failing (block, cell, class): smallest packed key wins
+        const unsigned long long key = ((unsigned long long)blk << 36) | ((unsigned long long)first << 4) | first_class;
+        atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
     }
 }
 
@@ -331,9 +330,8 @@ __global__ __launch_bounds__(256) void hsw_verify_frame_kernel(FrameVerifyParams
         if (p.pre_states[8 * (d.first_block + 1) + i] != p.next_states[8 * d.first_block + i]) fail(VERIFY_NEXT_STATE, i);
     if (bad) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&p.report->violations), (unsigned long long)bad);
-        const unsigned long long key = ((unsigned long long)d.first_block << 32) | first;
-        const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
-        if (key < old) p.report->first_class = first_class;
+        const unsigned long long key = ((unsigned long long)d.first_block << 36) | ((unsigned long long)first << 4) | first_class;
+        atomicMin(reinterpret_cast<unsigned long long *>(&p.report->first_key), key);
     }
 }
 
