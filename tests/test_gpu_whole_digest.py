@@ -388,3 +388,23 @@ def test_whole_region_montgomery_column_image(hsw, oracle, eng_int):
     assert np.array_equal(st["dense"], oracle.to_montgomery(ref["dense"])[:, : st["rows"]])
     for m, r in zip(msgs, res):
         assert r.output_bytes == hashlib.sha256(m).digest()
+
+
+@pytest.mark.parametrize("ncols", [1, 3])
+def test_whole_digest_other_spread_column_counts(hsw, oracle, ncols):
+    """SpreadConfig with 1 or 3 advice column pairs (spread.rs:25): the chip cursor wraps differently,
+    the gate / lookup streams do not change."""
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
+    msgs, sizes = [b"abc", bytes(range(90))], [64, 128]
+    cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=True, whole_digest=True)
+    res = cfg.digest_batch(msgs, [None, None])
+    assert cfg.verify()["violations"] == 0
+    st = cfg.streams()
+    cfg.close()
+    eng.close()
+    ref = oracle.digest_cells(msgs, sizes, None, True, num_advice_columns=ncols)
+    assert np.array_equal(st["gate"], ref["gate"]) and np.array_equal(st["lookup"], ref["lookup"])
+    assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]]) and np.array_equal(st["spread"], ref["spread"][:, : st["rows"]])
+    for m, r in zip(msgs, res):
+        assert r.output_bytes == hashlib.sha256(m).digest()
