@@ -175,7 +175,8 @@ int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
     hsw_shape shape;
     int rc = hsw_shape_query_ex(num_bits_lookup, num_advice_columns, mode, &shape);
     if (rc != HSW_OK) return rc;
-    if (mode == HSW_MODE_HALO2_INTERNALS && shape.limbs_per_spread != 2) return HSW_ERR_UNSUPPORTED;
+    if (mode == HSW_MODE_HALO2_INTERNALS && shape.limbs_per_spread > 4) return HSW_ERR_UNSUPPORTED;   // 2- / 1-bit tables: not built
+
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HSW_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return HSW_ERR_NO_DEVICE;

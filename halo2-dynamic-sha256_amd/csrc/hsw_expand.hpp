@@ -1084,14 +1084,16 @@ template <int L>
 hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
     if (p.flags & HSW_K_INTERNALS) {
-        // halo2-base internals (A3) are built for the reference's 8-bit table only
+        // halo2-base internals (A3): table widths 16, 8 and 4 bits (1, 2, 4 limbs per spread; the 2- and 1-bit
+        // tables would triple the build time for no known user); the wider tiles for the reference's 8-bit table only
         if constexpr (L == 2) {
             switch (tile) {
                 case 64: return launch_expand_LTR<L, 64, 32, true>(p, stream);
                 case 128: return launch_expand_LTR<L, 128, 16, true>(p, stream);
                 default: return launch_expand_LTR<L, 32, 64, true>(p, stream);
             }
-        } else return hipErrorInvalidValue;
+        } else if constexpr (L <= 4) return launch_expand_LTR<L, 32, 64, true>(p, stream);
+        else return hipErrorInvalidValue;
     }
     switch (tile) {
         case 6416: if constexpr (L == 2) return launch_expand_LTR<L, 64, 16, false>(p, stream); else return hipErrorInvalidValue;

@@ -179,3 +179,39 @@ def test_packing_combined_with_other_representations(hsw, oracle, eng_int, flags
     mask = np.ones(flat.shape[0], dtype=bool)
     mask[idx] = False
     assert (flat[mask] == np.uint64(2**64 - 1)).all()
+
+
+@pytest.mark.parametrize("bits,ncols", [(16, 2), (4, 2), (4, 3)])
+def test_internals_other_table_widths(hsw, oracle, bits, ncols):
+    """Internals mode (range_check rows + lookup column), digest frames and on-device verification for the
+    16- and 4-bit spread tables too."""
+    import hashlib
+    import torch
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, bits, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
+    try:
+        blocks, pre = _inputs(3, 40 + bits)
+        ref = oracle.Oracle(bits, ncols, check=True, internals=True).witness_blocks(blocks, pre, cursor0=5)
+        tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+        out = eng.witness_blocks_ex(tb, tp, cursor0=5, want_lookup=True)
+        eng.synchronize()
+        assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+        assert np.array_equal(out["lookup"].cpu().numpy().view(np.uint64), ref["lookup"])
+        assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+        assert eng.verify_blocks(tb, tp, out, cursor0=5, lookup=out["lookup"])["violations"] == 0
+        # whole digests
+        msgs, sizes = [b"abc", bytes(range(100))], [64, 128]
+        cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=True, whole_digest=True)
+        res = cfg.digest_batch(msgs, [None, None])
+        assert cfg.verify()["violations"] == 0
+        st = cfg.streams()
+        cfg.close()
+        refd = oracle.digest_cells(msgs, sizes, None, True, num_bits_lookup=bits, num_advice_columns=ncols)
+        assert np.array_equal(st["gate"], refd["gate"]) and np.array_equal(st["lookup"], refd["lookup"])
+        assert np.array_equal(st["dense"], refd["dense"][:, : st["rows"]])
+        for m, r in zip(msgs, res):
+            assert r.output_bytes == hashlib.sha256(m).digest()
+    finally:
+        eng.close()
+    with pytest.raises(hsw.HswError):                         # the 2- and 1-bit tables are not built in this mode
+        hsw.WitnessEngine(0, 2, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
