@@ -540,7 +540,7 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc["blocks_per_launch"] == n:
+            if pmc["algorithmic_bytes_per_launch"] == alg_bytes * n:      # same workload as this run
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
         except Exception:
             pass
