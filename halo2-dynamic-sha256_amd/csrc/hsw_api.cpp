@@ -15,6 +15,7 @@
 #include "../../include/hsw.h"
 #include "hsw_fr.hpp"
 #include "hsw_frame.hpp"
+#include "hsw_nounwind.hpp"
 #include "hsw_kernels.h"
 #include "hsw_layout.h"
 #include "hsw_structure.hpp"
@@ -105,11 +106,11 @@ const char *hsw_strerror(int status) {
 
 const char *hsw_last_error(const hsw_engine *e) { return e ? e->err.c_str() : ""; }
 
-int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out) {
+int hsw_shape_query(uint32_t num_bits_lookup, uint32_t num_advice_columns, hsw_shape *out) try {
     return hsw_shape_query_ex(num_bits_lookup, num_advice_columns, HSW_MODE_DEFAULT, out);
-}
+} HSW_NO_UNWIND
 
-int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode, hsw_shape *out) {
+int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, uint32_t mode, hsw_shape *out) try {
     if (!out) return HSW_ERR_INVALID_ARG;
     if (mode != HSW_MODE_DEFAULT && mode != HSW_MODE_HALO2_INTERNALS) return HSW_ERR_INVALID_ARG;
     const bool rc = mode == HSW_MODE_HALO2_INTERNALS;
@@ -128,9 +129,9 @@ int hsw_shape_query_ex(uint32_t num_bits_lookup, uint32_t num_advice_columns, ui
         default: return HSW_ERR_SHAPE;
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out) {
+int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *spread_out) try {
     if (num_bits_lookup == 0 || num_bits_lookup > 16 || 16 % num_bits_lookup != 0) return HSW_ERR_SHAPE;
     for (uint64_t idx = 0; idx < (1ull << num_bits_lookup); idx++) {              // spread.rs:169-189
         uint64_t sp = 0;
@@ -139,11 +140,11 @@ int hsw_spread_table(uint32_t num_bits_lookup, uint64_t *dense_out, uint64_t *sp
         if (spread_out) spread_out[idx] = sp;
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 uint32_t hsw_cell_bytes(uint32_t flags) { return (flags & HSW_REPR_COMPACT64) ? 8u : HSW_CELL_BYTES; }
 
-int hsw_neg_cells(const hsw_shape *s, uint32_t *out, size_t cap, size_t *n) {
+int hsw_neg_cells(const hsw_shape *s, uint32_t *out, size_t cap, size_t *n) try {
     if (!s || s->cells_per_round == 0) return HSW_ERR_INVALID_ARG;
     if (n) *n = 256;
     if (out) {
@@ -155,7 +156,7 @@ int hsw_neg_cells(const hsw_shape *s, uint32_t *out, size_t cap, size_t *n) {
                 out[4 * r + k] = s->off_rounds + r * s->cells_per_round + s->cells_per_sigma + in_ch[k];
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) {
     if (!s || s->num_advice_columns == 0 || s->limb_calls_per_block == 0) return 0;
@@ -164,12 +165,12 @@ uint64_t hsw_chip_rows(const hsw_shape *s, uint64_t cursor0, uint64_t n_blocks) 
 }
 
 int hsw_engine_create(int device, void *hip_stream, uint32_t num_bits_lookup,
-                      uint32_t num_advice_columns, hsw_engine **out) {
+                      uint32_t num_advice_columns, hsw_engine **out) try {
     return hsw_engine_create_ex(device, hip_stream, num_bits_lookup, num_advice_columns, HSW_MODE_DEFAULT, out);
-}
+} HSW_NO_UNWIND
 
 int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
-                         uint32_t num_advice_columns, uint32_t mode, hsw_engine **out) {
+                         uint32_t num_advice_columns, uint32_t mode, hsw_engine **out) try {
     if (!out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape shape;
@@ -196,7 +197,7 @@ int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
     }
     *out = e;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 static void free_pipeline(hsw_engine *e) {
     for (auto &s : e->slot) {
@@ -229,28 +230,28 @@ void hsw_engine_destroy(hsw_engine *e) {
     delete e;
 }
 
-int hsw_engine_shape(const hsw_engine *e, hsw_shape *out) {
+int hsw_engine_shape(const hsw_engine *e, hsw_shape *out) try {
     if (!e || !out) return HSW_ERR_INVALID_ARG;
     *out = e->shape;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device) {
+int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     if (hip_stream) *hip_stream = e->stream;
     if (device) *device = e->device;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_engine_synchronize(hsw_engine *e) {
+int hsw_engine_synchronize(hsw_engine *e) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     DeviceScope ds(e->device);
     hipError_t he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipStreamSynchronize", he);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
+int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
     if (!e || !name) return HSW_ERR_INVALID_ARG;
     if (std::strcmp(name, "parts") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
@@ -275,16 +276,16 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) {
         return HSW_OK;
     }
     return set_err(e, HSW_ERR_INVALID_ARG, "unknown option");
-}
+} HSW_NO_UNWIND
 
-int hsw_set_timing(hsw_engine *e, int enabled) {
+int hsw_set_timing(hsw_engine *e, int enabled) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     e->timing = enabled != 0;
     e->timed = false;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_last_kernel_ms(hsw_engine *e, float *ms) {
+int hsw_last_kernel_ms(hsw_engine *e, float *ms) try {
     if (!e || !ms) return HSW_ERR_INVALID_ARG;
     if (!e->timed) return set_err(e, HSW_ERR_INVALID_ARG, "no timed launch (call hsw_set_timing(e, 1) first)");
     DeviceScope ds(e->device);
@@ -293,21 +294,21 @@ int hsw_last_kernel_ms(hsw_engine *e, float *ms) {
     he = hipEventElapsedTime(ms, e->ev0, e->ev1);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventElapsedTime", he);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d_pre_states,
                        size_t n_blocks, uint64_t spread_cursor0, void *d_gate, void *d_chip_dense,
                        void *d_chip_spread, size_t chip_col_stride, uint32_t *d_next_states,
-                       uint32_t flags) {
+                       uint32_t flags) try {
     hsw_witness_args a{};
     a.d_blocks = d_blocks; a.d_pre_states = d_pre_states; a.n_blocks = n_blocks;
     a.spread_cursor0 = spread_cursor0; a.d_gate = d_gate; a.d_chip_dense = d_chip_dense;
     a.d_chip_spread = d_chip_spread; a.chip_col_stride = chip_col_stride;
     a.d_next_states = d_next_states; a.flags = flags;
     return hsw_witness_blocks_ex(e, &a);
-}
+} HSW_NO_UNWIND
 
-int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
+int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
     if (!e || !args) return HSW_ERR_INVALID_ARG;
     const uint8_t *d_blocks = args->d_blocks;
     const uint32_t *d_pre_states = args->d_pre_states;
@@ -427,9 +428,9 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) {
         e->timed = true;
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls) {
+int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls) try {
     if (!shape || shape->limbs_per_spread == 0) return HSW_ERR_INVALID_ARG;
     const std::vector<uint8_t> lens =
         hsw::TapeBuilder((int)shape->limbs_per_spread, shape->mode == HSW_MODE_HALO2_INTERNALS).block();
@@ -439,10 +440,10 @@ int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t 
         std::memcpy(lens_out, lens.data(), lens.size());
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_row, uint64_t max_rows,
-                        hsw_pack_plan *out) {
+                        hsw_pack_plan *out) try {
     if (!shape || !out || shape->limbs_per_spread == 0) return HSW_ERR_INVALID_ARG;
     if (max_rows < 8 || start_row >= max_rows) return HSW_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
@@ -473,9 +474,9 @@ int hsw_pack_plan_query(const hsw_shape *shape, size_t n_blocks, uint64_t start_
     out->span_cells = cell + gaps;
     out->end_row = row;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes) {
+int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes) try {
     if (!e || (bytes && (!host_dst || !d_src))) return HSW_ERR_INVALID_ARG;
     if (bytes == 0) return HSW_OK;
     DeviceScope ds(e->device);
@@ -484,9 +485,9 @@ int hsw_download(hsw_engine *e, void *host_dst, const void *d_src, size_t bytes)
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_download", he);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms) {
+int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms) try {
     if (!e || !d_buf || !ms || ((uintptr_t)d_buf & 15u)) return HSW_ERR_INVALID_ARG;
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
@@ -498,11 +499,11 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms) {
     e->timed = false;
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hsw_fill_calibrate", he);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
                      size_t blocks_per_message, const uint32_t *d_init_states,
-                     uint32_t *d_pre_states) {
+                     uint32_t *d_pre_states) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     if (n_messages == 0 || blocks_per_message == 0) return HSW_OK;
     if (!d_blocks || !d_pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
@@ -514,7 +515,7 @@ int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
                                       d_pre_states, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_chain_kernel", he);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 // Host delivery, pipelined: chunks of blocks are expanded on the engine's stream
 // into one of two device staging slots while the previous slot drains to host
@@ -614,19 +615,19 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
     return rc;
 }
 
-int hsw_host_alloc(size_t bytes, void **out) {
+int hsw_host_alloc(size_t bytes, void **out) try {
     if (!out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hipError_t he = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
     if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 void hsw_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t *pre_states,
                             size_t n_blocks, uint64_t spread_cursor0, void *gate, void *chip_dense,
                             void *chip_spread, size_t chip_col_stride, uint32_t *next_states,
-                            uint32_t flags) {
+                            uint32_t flags) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     if (n_blocks == 0) return HSW_OK;
     if (!blocks || !pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
@@ -700,6 +701,6 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
     (void)hipFree(d_blocks); (void)hipFree(d_pre); (void)hipFree(d_next);
     (void)hipFree(d_gate); (void)hipFree(d_cd); (void)hipFree(d_cs);
     return rc;
-}
+} HSW_NO_UNWIND
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 
 #include "hsw_engine.hpp"
 #include "hsw_fr.hpp"
+#include "hsw_nounwind.hpp"
 #include "hsw_kernels.h"
 #include "hsw_structure.hpp"
 
@@ -12,7 +13,7 @@ extern "C" {
 
 int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, uint8_t *cell_kind,
                         int64_t *cell_ref, uint32_t *gate_rows, int64_t *assert_eq, int64_t *range,
-                        int64_t *lookup_src, int64_t *chip, int64_t *next_state) {
+                        int64_t *lookup_src, int64_t *chip, int64_t *next_state) try {
     if (!shape || shape->limbs_per_spread == 0 || 16 % shape->limbs_per_spread != 0) return HSW_ERR_INVALID_ARG;
     const hsw::BlockStructure st =
         hsw::StructureBuilder((int)shape->limbs_per_spread, shape->mode == HSW_MODE_HALO2_INTERNALS).block();
@@ -36,14 +37,15 @@ int hsw_block_structure(const hsw_shape *shape, hsw_structure_counts *counts, ui
     if (chip && !st.chip.empty()) std::memcpy(chip, st.chip.data(), st.chip.size() * sizeof(int64_t));
     if (next_state) std::memcpy(next_state, st.next_state, sizeof st.next_state);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 // ------------------------------------------------------------ digest frames
 int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
-                    hsw_frame_shape *out) {
+                    hsw_frame_shape *out) try {
     if (!shape || !out) return HSW_ERR_INVALID_ARG;
     if (shape->mode != HSW_MODE_HALO2_INTERNALS) return HSW_ERR_INVALID_ARG;   // a frame is halo2-base internals
     if (max_variable_byte_size % 64 != 0) return HSW_ERR_SHAPE;                 // lib.rs:57-59
+    if ((uint64_t)max_variable_byte_size > (1ull << 32)) return HSW_ERR_TOO_LARGE;   // FrameDesc::n_blocks is 32 bits
     const bool rc = is_input_range_check != 0;
     const uint64_t nb = max_variable_byte_size / 64;
     out->n_blocks = nb;
@@ -56,15 +58,16 @@ int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int i
     out->digest_cells = out->prologue_cells + nb * shape->gate_cells_per_block + out->epilogue_cells;
     out->digest_lookups = out->prologue_lookups + nb * shape->lookup_cells_per_block + out->epilogue_lookups;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
-                   int section, uint8_t *lens_out, size_t cap, size_t *n_calls) {
+                   int section, uint8_t *lens_out, size_t cap, size_t *n_calls) try {
     hsw_frame_shape fs;
     const int rc = hsw_frame_query(shape, max_variable_byte_size, is_input_range_check, &fs);
     if (rc != HSW_OK) return rc;
     if (section != 0 && section != 1) return HSW_ERR_INVALID_ARG;
     std::vector<uint8_t> lens;
+    lens.reserve((size_t)(section == 0 ? fs.prologue_calls : fs.epilogue_calls));
     if (section == 0) {
         // lib.rs:124-165: lw, lw, mul, add, sub, is_less_than (7), its range_check (4), is_zero (8), lw, sub, 8 x lw
         static const uint8_t fixed[] = {1, 1, 4, 4, 4, 7, 4, 8, 1, 4, 1, 1, 1, 1, 1, 1, 1, 1};
@@ -87,12 +90,21 @@ int hsw_frame_tape(const hsw_shape *shape, size_t max_variable_byte_size, int is
         std::memcpy(lens_out, lens.data(), lens.size());
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 // ------------------------------------------------------------ on-device verification
 static int ensure_structure(hsw_engine *e) {
     if (e->d_structure) return HSW_OK;
     const hsw::BlockStructure st = hsw::StructureBuilder(e->limbs, e->mode == HSW_MODE_HALO2_INTERNALS).block();
+    // the kernel checks constants / copies while it walks the gate rows: every such cell must sit in one
+    std::vector<uint8_t> in_row(st.kind.size(), 0);
+    for (uint32_t r : st.gate_rows) for (int j = 0; j < 4; j++) in_row[r + j] = 1;
+    uint64_t fixed = 0;
+    for (size_t c = 0; c < st.kind.size(); c++) {
+        if (st.kind[c] != 0 && !in_row[c])
+            return set_err(e, HSW_ERR_UNSUPPORTED, "structure has a fixed / copied cell outside every gate row");
+        fixed += st.kind[c] != 0;
+    }
     // one device allocation: [ref | assert_eq | range | chip | lookup_src | next_state | gate_rows | kind]
     const size_t n_i64 = st.ref.size() + st.assert_eq.size() + st.range.size() + st.chip.size() + st.lookup_src.size() + 8;
     const size_t bytes = n_i64 * 8 + st.gate_rows.size() * 4 + st.kind.size();
@@ -125,20 +137,11 @@ static int ensure_structure(hsw_engine *e) {
     p.n_range = (uint32_t)(st.range.size() / 2);
     p.limb_calls = (uint32_t)(st.chip.size() / 2);
     p.lookup_cells = (uint32_t)st.lookup_src.size();
-    // the kernel checks constants / copies while it walks the gate rows: every such cell must sit in one
-    std::vector<uint8_t> in_row(st.kind.size(), 0);
-    for (uint32_t r : st.gate_rows) for (int j = 0; j < 4; j++) in_row[r + j] = 1;
-    uint64_t fixed = 0;
-    for (size_t c = 0; c < st.kind.size(); c++) {
-        if (st.kind[c] != 0 && !in_row[c]) { (void)hipFree(d); (void)hipFree(e->d_report); e->d_structure = nullptr; e->d_report = nullptr;
-                                             return set_err(e, HSW_ERR_UNSUPPORTED, "structure has a fixed / copied cell outside every gate row"); }
-        fixed += st.kind[c] != 0;
-    }
     e->verify_checks_per_block = fixed + p.n_rows + p.n_assert_eq + p.n_range;
     return HSW_OK;
 }
 
-int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_report *report) {
+int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_report *report) try {
     if (!e || !args || !report) return HSW_ERR_INVALID_ARG;
     std::memset(report, 0, sizeof *report);
     if (args->n_blocks == 0) return HSW_OK;
@@ -191,11 +194,11 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
         report->first_class = (uint32_t)(got.first_key & 15u);
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
                       const uint32_t *d_pre_states, const uint32_t *d_next_states, const void *d_gate,
-                      const void *d_lookup, const hsw_pack_plan *pack, uint32_t flags, hsw_verify_report *report) {
+                      const void *d_lookup, const hsw_pack_plan *pack, uint32_t flags, hsw_verify_report *report) try {
     if (!e || !report) return HSW_ERR_INVALID_ARG;
     std::memset(report, 0, sizeof *report);
     if (n == 0) return HSW_OK;
@@ -292,12 +295,12 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
         report->first_class = (uint32_t)(got.first_key & 15u);
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_frame_structure(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
                         int section, hsw_frame_structure_counts *counts, uint8_t *cell_kind, int64_t *cell_ref,
                         uint32_t *gate_rows, int64_t *assert_eq, int64_t *assert_const, int64_t *range,
-                        int64_t *lookup_src) {
+                        int64_t *lookup_src) try {
     hsw_frame_shape fs;
     const int rc = hsw_frame_query(shape, max_variable_byte_size, is_input_range_check, &fs);
     if (rc != HSW_OK) return rc;
@@ -324,7 +327,7 @@ int hsw_frame_structure(const hsw_shape *shape, size_t max_variable_byte_size, i
     if (range && !st.range.empty()) std::memcpy(range, st.range.data(), st.range.size() * sizeof(int64_t));
     if (lookup_src && !st.lookup_src.empty()) std::memcpy(lookup_src, st.lookup_src.data(), st.lookup_src.size() * sizeof(int64_t));
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 // k^-1 mod p for k < n, both representations, on the device (k = 0 -> 0, never read)
 static int ensure_inv_table(hsw_engine *e, size_t n) {
@@ -358,7 +361,7 @@ static int ensure_inv_table(hsw_engine *e, size_t n) {
 
 int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
                        const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
-                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags) {
+                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     if (n == 0) return HSW_OK;
     if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate)
@@ -429,6 +432,6 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
     slot.inflight = true;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 }  // extern "C"

@@ -11,6 +11,7 @@
 #include <immintrin.h>
 #endif
 
+#include "hsw_nounwind.hpp"
 #include "hsw_kernels.h"
 
 namespace hsw {
@@ -215,6 +216,10 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     if (rc != HSW_OK) return rc;
     if (s.num_bits_lookup != num_bits_lookup || s.num_advice_columns != num_advice_columns)
         return HSW_ERR_SHAPE;
+    int device = 0;
+    hsw_engine_stream(engine, nullptr, &device);
+    DeviceScope ds(device);                                   // the context's buffers live on the engine's GPU
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
     Context *c = new (std::nothrow) Context();
     if (!c) return HSW_ERR_NOMEM;
     c->engine = engine;
@@ -568,7 +573,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
         }
         off += pl.max_variable_round;
     }
-    ctx.batches.push_back(Context::BatchRecord{cur_hash_idx, n, b0, batch_blocks, zero_copy});
+    ctx.batches.push_back(Context::BatchRecord{cur_hash_idx, n, b0, batch_blocks, zero_copy, ctx.repr_flags});
     ctx.blocks_done += batch_blocks;
     if (ctx.whole) {
         ctx.gate_cursor = new_gate_cursor;
@@ -593,7 +598,7 @@ extern "C" {
 
 int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precomputed_input_len,
                        size_t max_variable_byte_size, uint8_t *blocks_out, uint32_t init_state_out[8],
-                       hsw_digest_info *info) {
+                       hsw_digest_info *info) try {
     hsw::DigestPlan plan;
     const int rc = hsw::digest_prepare(input, input_len, precomputed_input_len, max_variable_byte_size, &plan);
     if (rc != HSW_OK) return rc;
@@ -606,15 +611,15 @@ int hsw_digest_prepare(const uint8_t *input, size_t input_len, size_t precompute
         info->n_blocks = plan.max_variable_round;
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
-                      int is_input_range_check, hsw_gadget **out) {
+                      int is_input_range_check, hsw_gadget **out) try {
     return hsw_gadget_create_ex(e, max_variable_byte_sizes, n_hashes, is_input_range_check, 0, out);
-}
+} HSW_NO_UNWIND
 
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
-                         int is_input_range_check, uint32_t flags, hsw_gadget **out) {
+                         int is_input_range_check, uint32_t flags, hsw_gadget **out) try {
     if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
     if (flags & ~HSW_GADGET_WHOLE_DIGEST) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
@@ -630,7 +635,7 @@ int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, s
     if (rc != HSW_OK) { delete g; return rc; }
     *out = g;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 void hsw_gadget_destroy(hsw_gadget *g) {
     if (!g) return;
@@ -653,7 +658,7 @@ static void fill_result(const hsw::AssignedHashResult &r, hsw_hash_result *o) {
 }
 
 int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *inputs, const size_t *input_lens,
-                            const size_t *precomputed_input_lens, hsw_hash_result *results) {
+                            const size_t *precomputed_input_lens, hsw_hash_result *results) try {
     if (!g || !results) return HSW_ERR_INVALID_ARG;
     std::vector<hsw::AssignedHashResult> rs(n);
     const int rc = g->cfg.digest_batch(*g->ctx, n, inputs, input_lens, precomputed_input_lens, rs.data());
@@ -663,14 +668,14 @@ int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *input
         g->results.push_back(std::move(rs[i]));
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 int hsw_gadget_digest(hsw_gadget *g, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
-                      hsw_hash_result *result) {
+                      hsw_hash_result *result) try {
     return hsw_gadget_digest_batch(g, 1, &input, &input_len, &precomputed_input_len, result);
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
+int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) try {
     if (!g || !view) return HSW_ERR_INVALID_ARG;
     view->d_gate = g->ctx->d_gate;
     view->d_chip_dense = g->ctx->d_chip_dense;
@@ -689,9 +694,9 @@ int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) {
     view->max_rows = g->ctx->max_rows;
     view->columns = g->ctx->columns;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len) {
+int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len) try {
     if (!g || hash_idx >= g->results.size()) return HSW_ERR_INVALID_ARG;
     const std::vector<uint8_t> &b = g->results[hash_idx].input_bytes;
     if (len) *len = b.size();
@@ -700,16 +705,16 @@ int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t 
         if (!b.empty()) std::memcpy(out, b.data(), b.size());
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns) {
+int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns) try {
     if (!g) return HSW_ERR_INVALID_ARG;
     const int rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
     if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
     return rc;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_reset(hsw_gadget *g) {
+int hsw_gadget_reset(hsw_gadget *g) try {
     if (!g) return HSW_ERR_INVALID_ARG;
     const int rc = hsw_engine_synchronize(g->ctx->engine);
     if (rc != HSW_OK) return rc;
@@ -722,9 +727,9 @@ int hsw_gadget_reset(hsw_gadget *g) {
     g->cfg.cur_hash_idx = 0;            // lib.rs:66
     g->results.clear();
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) {
+int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) try {
     if (!g || !dst) return HSW_ERR_INVALID_ARG;
     hsw::Context &c = *g->ctx;
     hipStream_t stream = nullptr;
@@ -762,9 +767,9 @@ int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) {
     }
     if (he == hipSuccess) he = hipStreamSynchronize(stream);
     return he == hipSuccess ? HSW_OK : HSW_ERR_HIP;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) {
+int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {
     if (!g || hash_idx > g->cfg.max_variable_byte_sizes.size()) return HSW_ERR_INVALID_ARG;
     int rc = hsw_engine_synchronize(g->ctx->engine);
     if (rc != HSW_OK) return rc;
@@ -792,9 +797,9 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) {
     g->results.clear();
     g->results.resize(hash_idx);        // keeps hash_idx -> result indexing of hsw_gadget_input_bytes
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
+int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) try {
     if (!g || !report) return HSW_ERR_INVALID_ARG;
     std::memset(report, 0, sizeof *report);
     hsw::Context &c = *g->ctx;
@@ -823,7 +828,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
             a.d_chip_spread = static_cast<uint8_t *>(c.d_chip_spread) + (size_t)row_shift * cb;
             a.chip_col_stride = c.chip_col_stride;
             a.d_next_states = c.d_next_states + 8 * b.first_block;
-            a.flags = c.repr_flags;
+            a.flags = b.repr_flags;
             hsw_verify_report r;
             const int rc = hsw_verify_blocks(c.engine, &a, &r);
             if (rc != HSW_OK) return rc;
@@ -851,7 +856,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
             a.d_lookup = static_cast<uint8_t *>(c.d_lookup) + (size_t)r0.block_lookup * cb;
             a.frame_every = nb; a.frame_cells = fs.epilogue_cells + fs.prologue_cells;
             a.frame_lookups = fs.epilogue_lookups + fs.prologue_lookups;
-            a.flags = c.repr_flags;
+            a.flags = b.repr_flags;
             hsw_pack_plan rel{};
             if (c.max_rows) {
                 rel.n_breaks = abs_plan.n_breaks;
@@ -879,7 +884,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
                 blk += rk.n_blocks;
             }
             rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), c.d_blocks, c.d_pre_states, c.d_next_states, c.d_gate,
-                                   c.d_lookup, c.max_rows ? &abs_plan : nullptr, c.repr_flags, &r);
+                                   c.d_lookup, c.max_rows ? &abs_plan : nullptr, b.repr_flags, &r);
             if (rc != HSW_OK) return rc;
             merge(r);
             ob += run_blocks;
@@ -887,21 +892,21 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) {
         }
     }
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) {
+int hsw_gadget_cell_position(const hsw_gadget *g, uint64_t cell, uint64_t *column, uint64_t *row) try {
     if (!g) return HSW_ERR_INVALID_ARG;
     g->ctx->position(cell, column, row);
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
-int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) {
+int hsw_gadget_set_repr(hsw_gadget *g, uint32_t repr) try {
     if (!g || (repr & ~HSW_REPR_MASK) || repr == HSW_REPR_MASK) return HSW_ERR_INVALID_ARG;
     if (g->ctx->whole && (repr & HSW_REPR_COMPACT64)) return HSW_ERR_UNSUPPORTED;   // frames hold full-width cells
     if (g->ctx->blocks_done != 0 && hsw_cell_bytes(repr) != hsw_cell_bytes(g->ctx->repr_flags))
         return HSW_ERR_INVALID_ARG;               // the cell size of a context's streams cannot change midway
     g->ctx->repr_flags = repr;
     return HSW_OK;
-}
+} HSW_NO_UNWIND
 
 }  // extern "C"

@@ -122,7 +122,7 @@ class Context {
     void *d_lookup = nullptr;
     uint64_t lookup_cursor = 0, lookup_capacity = 0;
     // what every digest_batch call wrote, for hsw_gadget_verify
-    struct BatchRecord { size_t first_digest, n_digests, first_block, n_blocks; bool inputs_in_pinned; };
+    struct BatchRecord { size_t first_digest, n_digests, first_block, n_blocks; bool inputs_in_pinned; uint32_t repr_flags; };
     std::vector<BatchRecord> batches;
     // FlexGate column image (set_columns): d_gate is `columns` advice columns of max_rows cells;
     // stream cell i sits at i + the gaps of all breaks at or before i (assumption A3-iii)

@@ -374,6 +374,8 @@ typedef struct hsw_frame_shape {
     uint64_t digest_cells;        /* prologue + n_blocks*G + epilogue; the zero cell is not counted */
     uint64_t digest_lookups;
 } hsw_frame_shape;
+/* HSW_ERR_SHAPE: max not a multiple of 64 (lib.rs:57-59); HSW_ERR_TOO_LARGE: max above 2^32 bytes
+ * (a frame counts its blocks in 32 bits). */
 int hsw_frame_query(const hsw_shape *shape, size_t max_variable_byte_size, int is_input_range_check,
                     hsw_frame_shape *out);
 /* The assign_region call lengths of the prologue (section 0) or epilogue

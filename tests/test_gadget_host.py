@@ -113,3 +113,32 @@ print(bytes(blocks).hex(), [int(x) for x in init], info["target_round"])
     for r in range(tr):
         st = O.plain_compress(st, __import__("numpy").frombuffer(blocks[64 * r: 64 * r + 64], dtype="uint8"))
     assert b"".join(int(x).to_bytes(4, "big") for x in st) == hashlib.sha256(msg).digest()
+
+
+def test_failed_host_allocation_comes_back_as_a_status_code():
+    """include/hsw.h: nothing unwinds across the boundary.  With the address space capped, a 2 GiB tape
+    cannot be allocated; the call must return HSW_ERR_NOMEM (csrc/hsw_nounwind.hpp), not terminate."""
+    import os, subprocess, sys
+    code = r"""
+import ctypes as C, importlib, resource, sys
+sys.path.insert(0, %r)
+N = importlib.import_module("halo2-dynamic-sha256_amd._native")
+L = N.lib()
+s = N.shape_query(8, 2, N.HSW_MODE_HALO2_INTERNALS)
+assert N.frame_query(s, 1 << 32).n_blocks == 1 << 26
+fs = N.FrameShape()
+print("over", L.hsw_frame_query(C.byref(s), (1 << 32) + 64, 0, C.byref(fs)))
+vsz = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (vsz + (256 << 20), vsz + (256 << 20)))
+n = C.c_size_t()
+print("tape", L.hsw_frame_tape(C.byref(s), 1 << 31, 0, 0, None, 0, C.byref(n)))
+print("small", L.hsw_frame_tape(C.byref(s), 1 << 10, 0, 0, None, 0, C.byref(n)), n.value)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    from importlib import import_module
+    N = import_module("halo2-dynamic-sha256_amd._native")
+    lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    assert int(lines["over"]) == N.HSW_ERR_TOO_LARGE
+    assert int(lines["tape"]) == N.HSW_ERR_NOMEM
+    assert lines["small"] == "0 %d" % (18 + 1024)

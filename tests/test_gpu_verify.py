@@ -201,6 +201,20 @@ def test_gadget_verify_block_stream_contexts(engine_factory, hsw):
     cfg.close()
 
 
+def test_gadget_verify_after_a_representation_change(engine_factory, hsw):
+    """set_repr between digests (same cell size): verify checks each batch in the form it was written in."""
+    eng = engine_factory(8, 2)
+    cfg = hsw.Sha256DynamicConfig(eng, [128, 128, 64], False)
+    cfg.digest(b"canonical cells")
+    cfg.set_repr(hsw._native.HSW_REPR_MONTGOMERY)
+    cfg.digest(b"montgomery cells")
+    cfg.set_repr(0)
+    cfg.digest(b"canonical again")
+    rep = cfg.verify()
+    assert rep["violations"] == 0 and rep["checks"] > 5 * 70000
+    cfg.close()
+
+
 def test_verify_shard_of_configs3_and_beyond(engine_factory):
     """BASELINE configs[3]'s per-GPU shard is 8,192 blocks (19.5 GB); twice that (39 GB, byte offsets far
     past 2^32 and cell indices past 2^30) generated at an odd cursor and checked in HBM by the product's
