@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Randomised differential run: HIP path (through the C ABI) vs the CPU oracle, bit for bit.
+
+Every iteration draws a point of the cross product the parametrised tests only sample:
+  block streams   mode (default / halo2 internals) x table width x advice columns x batch size (both
+                  sides of the 32-block split-phase threshold) x chip cursor x cell representation x
+                  tile / waves-per-block / split knobs x gate stream 0..3 cells off a 128-byte line x
+                  FlexGate column packing with a random start row / column height
+  whole digests   random message lists (lengths, maximum sizes, precomputed prefixes, input range checks,
+                  one batch or one call per digest, canonical / Montgomery, linear stream or column image)
+and compares every output cell with the oracle, plus the bytes around the outputs (must stay untouched).
+
+Test infrastructure (imports oracle/).  usage: python tests/fuzz_parity.py [seconds] [seed]
+tests/test_gpu_fuzz.py runs a short, fixed-seed slice of it in the GPU suite."""
+import ctypes as C
+import hashlib
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FILL = np.uint64(0xFFFFFFFFFFFFFFFF)
+P0 = 0x43e1f593f0000001
+
+
+class Fuzzer:
+    def __init__(self, seed=1):
+        import torch
+        self.torch = torch
+        self.hsw = importlib.import_module("halo2-dynamic-sha256_amd")
+        self.N = self.hsw._native
+        self.O = importlib.import_module("oracle.oracle")
+        self.rng = np.random.default_rng(seed)
+        self.engines = {}
+        self.stats = dict(block_runs=0, block_cells=0, digest_runs=0, digest_cells=0, skipped=0)
+
+    def engine(self, bits, ncols, internals):
+        key = (bits, ncols, internals)
+        if key not in self.engines:
+            mode = self.N.HSW_MODE_HALO2_INTERNALS if internals else self.N.HSW_MODE_DEFAULT
+            self.engines[key] = self.hsw.WitnessEngine(0, bits, ncols, mode=mode)
+        return self.engines[key]
+
+    def close(self):
+        for e in self.engines.values():
+            e.close()
+        self.engines = {}
+
+    # ---------------------------------------------------------------- block streams
+    def _expected(self, ref, eng, n, flags, internals):
+        """Oracle streams in the representation `flags` asks for: (gate, dense, spread, lookup)."""
+        N, O = self.N, self.O
+        lookup = ref.get("lookup") if internals else None
+        if flags == N.HSW_REPR_MONTGOMERY:
+            return (O.to_montgomery(ref["gate"]), O.to_montgomery(ref["dense"]), O.to_montgomery(ref["spread"]),
+                    O.to_montgomery(lookup) if lookup is not None else None)
+        if flags == N.HSW_REPR_COMPACT64:
+            G = eng.G
+            g = ref["gate"][:, 0].copy().reshape(n, G)
+            neg = N.neg_cells(eng.shape).astype(np.int64)
+            wide = (ref["gate"][:, 1:] != 0).any(axis=1).reshape(n, G)
+            mask = np.zeros(G, dtype=bool)
+            mask[neg] = True
+            assert not wide[:, ~mask].any()
+            vals = g[:, neg]
+            g[:, neg] = np.where(wide[:, neg], (np.uint64(P0) - vals).astype(np.uint64), vals)
+            return (g.reshape(-1, 1), ref["dense"][..., :1], ref["spread"][..., :1],
+                    lookup[:, :1] if lookup is not None else None)
+        return ref["gate"], ref["dense"], ref["spread"], lookup
+
+    def block_case(self):
+        rng, N, t = self.rng, self.N, self.torch
+        internals = bool(rng.integers(0, 2))
+        bits = int(rng.choice([16, 8, 4] if internals else [16, 8, 8, 4, 2, 1]))
+        ncols = int(rng.integers(1, 7))
+        n = int(rng.choice([1, 2, 3, 5, 8, 13, 31, 32, 33, 40]))
+        if bits <= 2:
+            n = min(n, 8)
+        cursor0 = int(rng.choice([0, 1, int(rng.integers(0, 10**6)), int(rng.integers(0, 2**40))]))
+        flags = int(rng.choice([0, N.HSW_REPR_MONTGOMERY, N.HSW_REPR_COMPACT64]))
+        tile, parts = [(0, 0), (32, 1), (32, 4), (32, 32), (64, 2), (64, 4), (64, 16), (128, 4), (128, 8), (128, 32),
+                       (0, 1), (0, 8)][int(rng.integers(0, 12))]
+        split = int(rng.choice([-1, -1, 0, 1]))
+        shift = int(rng.choice([0, 0, 1, 2, 3]))
+        pack = rng.random() < 0.4
+        desc = dict(kind="blocks", internals=internals, bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags,
+                    tile=tile, parts=parts, split=split, shift=shift, pack=pack)
+        self.current = desc
+        eng = self.engine(bits, ncols, internals)
+        G, LK = eng.G, eng.lookup_cells
+        plan, start_row, max_rows = None, 0, 0
+        if pack:
+            max_rows = int(rng.integers(G // 2 + 16, 3 * G))
+            start_row = int(rng.integers(0, max_rows))
+            desc.update(start_row=start_row, max_rows=max_rows)
+            try:
+                plan = N.pack_plan(eng.shape, n, start_row, max_rows)
+            except N.HswError:
+                self.stats["skipped"] += 1
+                return desc
+        blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+        pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+        if rng.random() < 0.1:
+            blocks[0] = 0 if rng.random() < 0.5 else 255
+            pre[0] = 0 if rng.random() < 0.5 else 0xFFFFFFFF
+        w = 1 if flags == N.HSW_REPR_COMPACT64 else 4
+        span = int(plan.span_cells) if plan is not None else n * G
+        # compact cells are 8 bytes: keep the stream 16-byte aligned (two cells per shift step)
+        lead = shift * (2 if w == 1 else 1)
+        big = t.full((span + lead + 8, w), -1, dtype=t.int64, device="cuda")
+        rows = eng.chip_rows(cursor0, n)
+        dense = t.full((ncols, rows + 2, w), -1, dtype=t.int64, device="cuda")
+        spread = t.full((ncols, rows + 2, w), -1, dtype=t.int64, device="cuda")
+        nxt = t.empty((n, 8), dtype=t.int32, device="cuda")
+        lookup = t.full((n * LK + 4, w), -1, dtype=t.int64, device="cuda") if internals else None
+        tb, tp = t.from_numpy(blocks).cuda(), t.from_numpy(pre.view(np.int32)).cuda()
+        a = N.WitnessArgs()
+        a.d_blocks, a.d_pre_states, a.n_blocks, a.spread_cursor0 = tb.data_ptr(), tp.data_ptr(), n, cursor0
+        a.d_gate = big.data_ptr() + lead * 8 * w
+        a.d_chip_dense, a.d_chip_spread, a.chip_col_stride = dense.data_ptr(), spread.data_ptr(), rows + 2
+        a.d_next_states = nxt.data_ptr()
+        a.d_lookup = lookup.data_ptr() if internals else None
+        a.flags = flags
+        a.pack = C.pointer(plan) if plan is not None else None
+        eng.set_option("tile", tile)
+        eng.set_option("parts", parts)
+        eng.set_option("split", split)
+        try:
+            rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
+            if rc == N.HSW_ERR_UNSUPPORTED:      # e.g. more than two column breaks inside one block
+                self.stats["skipped"] += 1
+                return desc
+            assert rc == 0, (rc, eng.lib.hsw_last_error(eng.h))
+            eng.synchronize()
+        finally:
+            eng.set_option("tile", 0)
+            eng.set_option("parts", 0)
+            eng.set_option("split", -1)
+        ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=cursor0)
+        eg, ed, es, el = self._expected(ref, eng, n, flags, internals)
+        flat = big.cpu().numpy().view(np.uint64)
+        if plan is not None:
+            lens = N.gate_tape(eng.shape).astype(np.int64)
+            # position of every cell under "row + len >= max_rows -> next column" (assumption A3-iii)
+            idx = np.empty(n * G, dtype=np.int64)
+            col, row, k = 0, start_row, 0
+            for _ in range(n):
+                if row + G + 4 < max_rows:
+                    idx[k:k + G] = col * max_rows + row - start_row + np.arange(G)
+                    row += G
+                    k += G
+                    continue
+                for ln in lens.tolist():
+                    if row + ln >= max_rows:
+                        col, row = col + 1, 0
+                    idx[k:k + ln] = col * max_rows + row - start_row + np.arange(ln)
+                    row += ln
+                    k += ln
+            idx += lead
+        else:
+            idx = lead + np.arange(n * G, dtype=np.int64)
+        got = flat[idx]
+        if not np.array_equal(got, eg):
+            bad = np.nonzero((got != eg).any(axis=1))[0]
+            raise AssertionError("gate stream differs at %d cells, first %d" % (len(bad), bad[0]))
+        mask = np.ones(flat.shape[0], dtype=bool)
+        mask[idx] = False
+        assert (flat[mask] == FILL).all(), "cells outside the stream were written"
+        d, s = dense.cpu().numpy().view(np.uint64), spread.cpu().numpy().view(np.uint64)
+        # rows the call owns; cells of the first / last row that belong to neighbouring calls keep the fill
+        first, last = cursor0 % ncols, (cursor0 + n * eng.limb_calls - 1) % ncols
+        own = np.ones((ncols, rows), dtype=bool)
+        own[:first, 0] = False
+        own[last + 1:, rows - 1] = False
+        assert np.array_equal(d[:, :rows][own], ed[:, :rows][own]), "chip dense cells differ"
+        assert np.array_equal(s[:, :rows][own], es[:, :rows][own]), "chip spread cells differ"
+        assert (d[:, :rows][~own] == FILL).all() and (s[:, :rows][~own] == FILL).all(), "neighbour's chip cells written"
+        assert (d[:, rows:] == FILL).all() and (s[:, rows:] == FILL).all()
+        assert np.array_equal(nxt.cpu().numpy().view(np.uint32), ref["next_states"]), "next states differ"
+        if internals:
+            lk = lookup.cpu().numpy().view(np.uint64)
+            assert np.array_equal(lk[: n * LK], el), "lookup column differs"
+            assert (lk[n * LK:] == FILL).all()
+        self.stats["block_runs"] += 1
+        self.stats["block_cells"] += n * (G + 2 * eng.limb_calls)
+        return desc
+
+    # ---------------------------------------------------------------- whole digests
+    def digest_case(self):
+        rng, N, hsw = self.rng, self.N, self.hsw
+        bits = int(rng.choice([8, 8, 8, 16, 4]))
+        ncols = int(rng.choice([2, 2, 1, 3]))
+        nd = int(rng.integers(1, 5))
+        equal = rng.random() < 0.4
+        sizes, msgs, pres = [], [], []
+        for i in range(nd):
+            nb = int(rng.choice([1, 2, 3, 4, 8])) if not (equal and sizes) else sizes[0] // 64
+            pre_rounds = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+            # total padded rounds must satisfy max(pre_rounds, 1) <= num_round <= pre_rounds + nb (lib.rs:89-90)
+            num_round = int(rng.integers(max(pre_rounds, 1), pre_rounds + nb + 1))
+            lo, hi = max(0, 64 * (num_round - 1) - 8), 64 * num_round - 9           # ceil((ln + 9) / 64) == num_round
+            ln = int(rng.integers(lo, hi + 1)) if rng.random() < 0.8 else int(rng.choice([lo, hi]))
+            sizes.append(64 * nb)
+            pres.append(64 * pre_rounds)
+            msgs.append(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+        rc = bool(rng.integers(0, 2))
+        batch = bool(rng.integers(0, 2))
+        mont = rng.random() < 0.35
+        columns = rng.random() < 0.4
+        desc = dict(kind="digests", bits=bits, ncols=ncols, sizes=sizes, lens=[len(m) for m in msgs], pres=pres, rc=rc,
+                    batch=batch, mont=mont, columns=columns)
+        self.current = desc
+        eng = self.engine(bits, ncols, True)
+        cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True)
+        try:
+            if mont:
+                cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+            max_rows = None
+            if columns:
+                max_rows = int(rng.integers(eng.G + 16, 4 * eng.G))
+                desc["max_rows"] = max_rows
+                try:
+                    cfg.set_columns(max_rows)
+                except hsw.HswError as ex:
+                    if ex.status in (N.HSW_ERR_TOO_LARGE, N.HSW_ERR_UNSUPPORTED):
+                        self.stats["skipped"] += 1
+                        return desc
+                    raise
+            res = cfg.digest_batch(msgs, pres) if batch else [cfg.digest(m, p) for m, p in zip(msgs, pres)]
+            st = cfg.streams()
+            rep = cfg.verify()
+        finally:
+            cfg.close()
+        ref = self.O.digest_cells(msgs, sizes, pres, rc, num_bits_lookup=bits, num_advice_columns=ncols)
+        for m, r in zip(msgs, res):
+            assert r.output_bytes == hashlib.sha256(m).digest(), "digest differs from SHA-256"
+        conv = self.O.to_montgomery if mont else (lambda x: x)
+        if columns:
+            # halo2-lib v0.2.x FlexGate::assign_region over the oracle's call tape (assumption A3-iii)
+            g = conv(ref["gate"])
+            cols, col, row, at = [np.zeros((max_rows, 4), dtype=np.uint64)], 0, 0, 0
+            for ln in ref["call_lens"].tolist():
+                if row + ln >= max_rows:
+                    cols.append(np.zeros((max_rows, 4), dtype=np.uint64))
+                    col, row = col + 1, 0
+                cols[col][row:row + ln] = g[at:at + ln]
+                row += ln
+                at += ln
+            assert at == len(g)
+            assert np.array_equal(st["gate"], np.stack(cols)), "column image differs"
+        else:
+            assert np.array_equal(st["gate"], conv(ref["gate"])), "whole-digest gate stream differs"
+        assert np.array_equal(st["lookup"], conv(ref["lookup"])), "lookup stream differs"
+        assert np.array_equal(st["dense"], conv(ref["dense"][:, : st["rows"]]))
+        assert np.array_equal(st["spread"], conv(ref["spread"][:, : st["rows"]]))
+        assert rep["violations"] == 0, rep
+        self.stats["digest_runs"] += 1
+        self.stats["digest_cells"] += len(ref["gate"])
+        return desc
+
+    def run(self, seconds=None, iterations=None, log=None):
+        t0 = time.time()
+        it = 0
+        last = t0
+        while (seconds is None or time.time() - t0 < seconds) and (iterations is None or it < iterations):
+            self.current = None
+            try:
+                self.block_case() if self.rng.random() < 0.7 else self.digest_case()
+            except Exception:
+                print("FAILED case:", self.current, file=sys.stderr, flush=True)
+                raise
+            it += 1
+            if log and time.time() - last > 20:
+                last = time.time()
+                print("%6.0f s  %s" % (last - t0, self.stats), file=log, flush=True)
+        return dict(self.stats, iterations=it, seconds=round(time.time() - t0, 1))
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    f = Fuzzer(seed)
+    try:
+        out = f.run(seconds=secs, log=sys.stdout)
+    finally:
+        f.close()
+    import json
+    print(json.dumps(dict(out, seed=seed, violations=0)))
