@@ -590,13 +590,18 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
             if (want_gate && (he = hipMemcpyAsync(static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
                                                   nb * G * cb, hipMemcpyDeviceToHost, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
             if (want_chip) {
+                // only the last chunk can end inside a row: the cells of that row past the call's last limb
+                // belong to the next call and must keep what the caller's buffer holds
+                const size_t tail = (size_t)((cur + (uint64_t)nb * LC) % ncols);
                 for (size_t c = 0; c < ncols && he == hipSuccess; c++) {
                     const size_t dst = (c * chip_col_stride + row_off) * cb, src = c * e->slot_rows * cb;
+                    const size_t own = rows - ((tail != 0 && c >= tail) ? 1 : 0);
+                    if (own == 0) continue;
                     he = hipMemcpyAsync(static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
-                                        rows * cb, hipMemcpyDeviceToHost, e->copy_stream);
+                                        own * cb, hipMemcpyDeviceToHost, e->copy_stream);
                     if (he == hipSuccess)
                         he = hipMemcpyAsync(static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
-                                            rows * cb, hipMemcpyDeviceToHost, e->copy_stream);
+                                            own * cb, hipMemcpyDeviceToHost, e->copy_stream);
                 }
                 if (he != hipSuccess) { fail("D2H chip columns"); break; }
             }

@@ -305,7 +305,9 @@ int hsw_sha256_chain(hsw_engine *e, const uint8_t *d_blocks, size_t n_messages,
  * overlap), and synchronizes.  Any output pointer may be NULL (stream skipped).
  * Fastest with pinned output buffers (hsw_host_alloc, or HSW_HOST_REGISTER);
  * PCIe-bound either way: 2.39 MB per block.  (If spread_cursor0 is not a
- * multiple of num_advice_columns the call falls back to one unpipelined pass.) */
+ * multiple of num_advice_columns the call falls back to one unpipelined pass.)
+ * As on the device, chip cells of the first / last row that belong to the
+ * neighbouring calls keep what the caller's buffers hold. */
 int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t *pre_states,
                             size_t n_blocks, uint64_t spread_cursor0, void *gate,
                             void *chip_dense, void *chip_spread, size_t chip_col_stride,

@@ -6,6 +6,7 @@ Every iteration draws a point of the cross product the parametrised tests only s
                   sides of the 32-block split-phase threshold) x chip cursor x cell representation x
                   tile / waves-per-block / split knobs x gate stream 0..3 cells off a 128-byte line x
                   FlexGate column packing with a random start row / column height
+  host delivery   hsw_witness_blocks_host around its 128-block chunking, both cursor alignments, pinned or not
   whole digests   random message lists (lengths, maximum sizes, precomputed prefixes, input range checks,
                   one batch or one call per digest, canonical / Montgomery, linear stream or column image)
 and compares every output cell with the oracle, plus the bytes around the outputs (must stay untouched).
@@ -191,6 +192,32 @@ class Fuzzer:
         self.stats["block_cells"] += n * (G + 2 * eng.limb_calls)
         return desc
 
+    # ---------------------------------------------------------------- host delivery
+    def host_case(self):
+        """hsw_witness_blocks_host: numpy in, numpy out -- the pipelined path (cursor a multiple of the column
+        count: 128-block chunks through two staging slots) and the single-shot one."""
+        rng, N = self.rng, self.N
+        bits = int(rng.choice([8, 8, 16, 4]))
+        ncols = int(rng.integers(1, 6))
+        n = int(rng.choice([1, 7, 127, 128, 129, 200, 257, 300]))
+        cursor0 = int(rng.integers(0, 10**5))
+        if rng.random() < 0.6:
+            cursor0 -= cursor0 % ncols
+        flags = int(rng.choice([0, N.HSW_REPR_MONTGOMERY, N.HSW_REPR_COMPACT64]))
+        pinned = bool(rng.integers(0, 2))
+        self.current = dict(kind="host", bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags, pinned=pinned)
+        eng = self.engine(bits, ncols, False)
+        blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+        pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+        got = eng.witness_blocks_host(blocks, pre, cursor0=cursor0, flags=flags, pinned=pinned)
+        ref = self.O.Oracle(bits, ncols, check=False).witness_blocks(blocks, pre, cursor0=cursor0)
+        eg, ed, es, _ = self._expected(ref, eng, n, flags, False)
+        assert np.array_equal(got["gate"], eg), "host gate stream differs"
+        assert np.array_equal(got["dense"], ed) and np.array_equal(got["spread"], es), "host chip columns differ"
+        assert np.array_equal(got["next_states"], ref["next_states"])
+        self.stats["host_runs"] = self.stats.get("host_runs", 0) + 1
+        self.stats["block_cells"] += n * (eng.G + 2 * eng.limb_calls)
+
     # ---------------------------------------------------------------- whole digests
     def digest_case(self):
         rng, N, hsw = self.rng, self.N, self.hsw
@@ -271,7 +298,8 @@ class Fuzzer:
         while (seconds is None or time.time() - t0 < seconds) and (iterations is None or it < iterations):
             self.current = None
             try:
-                self.block_case() if self.rng.random() < 0.7 else self.digest_case()
+                u = self.rng.random()
+                self.block_case() if u < 0.65 else self.digest_case() if u < 0.95 else self.host_case()
             except Exception:
                 print("FAILED case:", self.current, file=sys.stderr, flush=True)
                 raise

@@ -358,6 +358,22 @@ def test_pipelined_host_delivery(engine_factory, oracle, hsw, ncols, n, pinned, 
     assert np.array_equal(got["next_states"], ref["next_states"])
 
 
+def test_pipelined_host_delivery_leaves_the_next_calls_cells_alone(engine_factory, oracle, hsw):
+    """A call that ends inside a chip row (8,240 limbs, 3 columns): the cell of that row past its last limb
+    belongs to the next call -- the staging slot holds stale data there (dirtied by the first call) and
+    must not be copied out.  Found by tests/fuzz_parity.py."""
+    eng = engine_factory(4, 3)
+    blocks, pre = _rand_inputs(3, 5150)
+    eng.witness_blocks_host(blocks, pre, cursor0=0, flags=hsw.HSW_REPR_MONTGOMERY, pinned=False)      # dirties the slots
+    got = eng.witness_blocks_host(blocks[:1], pre[:1], cursor0=34929, flags=hsw.HSW_REPR_MONTGOMERY, pinned=False)
+    ref = oracle.Oracle(4, 3, check=False).witness_blocks(blocks[:1], pre[:1], cursor0=34929)
+    assert (34929 + eng.limb_calls) % 3 == 2
+    assert np.array_equal(got["dense"], oracle.to_montgomery(ref["dense"]))
+    assert np.array_equal(got["spread"], oracle.to_montgomery(ref["spread"]))
+    assert not got["dense"][2, -1].any() and not got["spread"][2, -1].any()       # the next call's cell: untouched
+    assert np.array_equal(got["gate"], oracle.to_montgomery(ref["gate"]))
+
+
 def test_hip_graph_capture_and_replay(hsw, oracle):
     """The launch path does no allocation / synchronization, so chain + expand can
     be captured into a HIP graph and replayed on new inputs (launch-bound small
