@@ -170,7 +170,7 @@ class WitnessEngine:
         out["_keep"] = keep
         return out
 
-    def verify_blocks(self, blocks, pre_states, out, cursor0=0, lookup=None, check_chip=True, check_next=True):
+    def verify_blocks(self, blocks, pre_states, out, cursor0=0, lookup=None, check_chip=True, check_next=True, flags=0):
         """hsw_verify_blocks: on-device check of the streams in `out` (as written by witness_blocks for
         these inputs) against the gadget's constraint system.  Returns the report as a dict."""
         a = N.WitnessArgs()
@@ -184,6 +184,7 @@ class WitnessEngine:
             a.d_next_states = out["next_states"].data_ptr()
         if lookup is not None:
             a.d_lookup = lookup.data_ptr()
+        a.flags = flags                      # the representation the streams were written in (canonical / Montgomery)
         rep = N.VerifyReport()
         self._ok(self.lib.hsw_verify_blocks(self.h, C.byref(a), C.byref(rep)))
         return dict(violations=int(rep.violations), checks=int(rep.checks), first_block=int(rep.first_block),
