@@ -6,6 +6,8 @@ Every iteration draws a point of the cross product the parametrised tests only s
                   sides of the 32-block split-phase threshold) x chip cursor x cell representation x
                   tile / waves-per-block / split knobs x gate stream 0..3 cells off a 128-byte line x
                   FlexGate column packing with a random start row / column height
+  gadget streams  Sha256DynamicConfig.digest / digest_batch in random groupings (both chaining sides, zero-copy
+                  or staged inputs, reset), canonical / Montgomery
   host delivery   hsw_witness_blocks_host around its 128-block chunking, both cursor alignments, pinned or not
   whole digests   random message lists (lengths, maximum sizes, precomputed prefixes, input range checks,
                   one batch or one call per digest, canonical / Montgomery, linear stream or column image)
@@ -192,6 +194,72 @@ class Fuzzer:
         self.stats["block_cells"] += n * (G + 2 * eng.limb_calls)
         return desc
 
+    # ---------------------------------------------------------------- gadget block streams
+    def _random_digests(self, nd, nb_choices, equal=False):
+        rng = self.rng
+        sizes, msgs, pres = [], [], []
+        for _ in range(nd):
+            nb = int(rng.choice(nb_choices)) if not (equal and sizes) else sizes[0] // 64
+            pre_rounds = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+            # total padded rounds must satisfy max(pre_rounds, 1) <= num_round <= pre_rounds + nb (lib.rs:89-90)
+            num_round = int(rng.integers(max(pre_rounds, 1), pre_rounds + nb + 1))
+            lo, hi = max(0, 64 * (num_round - 1) - 8), 64 * num_round - 9           # ceil((ln + 9) / 64) == num_round
+            ln = int(rng.integers(lo, hi + 1)) if rng.random() < 0.8 else int(rng.choice([lo, hi]))
+            sizes.append(64 * nb)
+            pres.append(64 * pre_rounds)
+            msgs.append(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+        return sizes, msgs, pres
+
+    def gadget_case(self):
+        """Sha256DynamicConfig.digest as block streams (the f1 front-end): random groupings of digest /
+        digest_batch calls in one context (host- or GPU-side chaining, zero-copy or staged inputs), optionally
+        a reset and a second pass; the concatenated streams against the oracle's."""
+        rng, N, hsw = self.rng, self.N, self.hsw
+        internals = rng.random() < 0.3
+        bits = int(rng.choice([8, 8, 16, 4]))
+        ncols = int(rng.integers(1, 5))
+        nd = int(rng.integers(1, 7))
+        sizes, msgs, pres = self._random_digests(nd, [1, 1, 2, 3, 4, 8, 16, 40])
+        rc = bool(rng.integers(0, 2))
+        mont = rng.random() < 0.4
+        again = rng.random() < 0.25
+        self.current = dict(kind="gadget", internals=internals, bits=bits, ncols=ncols, sizes=sizes,
+                            lens=[len(m) for m in msgs], pres=pres, rc=rc, mont=mont, again=again)
+        eng = self.engine(bits, ncols, internals)
+        cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc)
+        try:
+            if mont:
+                cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+            for rnd in range(2 if again else 1):
+                if rnd:
+                    cfg.reset()
+                res, i = [], 0
+                while i < nd:
+                    k = int(rng.integers(1, nd - i + 1))
+                    if k == 1 and rng.random() < 0.5:
+                        res.append(cfg.digest(msgs[i], pres[i]))
+                    else:
+                        res += cfg.digest_batch(msgs[i:i + k], pres[i:i + k])
+                    i += k
+            st = cfg.streams()
+            rep = cfg.verify()
+        finally:
+            cfg.close()
+        o = self.O.Oracle(bits, ncols, check=False, internals=internals)
+        ds = [o.digest(m, mx, p) for m, mx, p in zip(msgs, sizes, pres)]
+        blocks = np.concatenate([d["blocks"][: mx // 64] for d, mx in zip(ds, sizes)])
+        pre = np.concatenate([d["pre_states"][: mx // 64] for d, mx in zip(ds, sizes)])
+        ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=0)
+        conv = self.O.to_montgomery if mont else (lambda x: x)
+        for m, r, d in zip(msgs, res, ds):
+            assert r.output_bytes == hashlib.sha256(m).digest() == d["digest"], "digest differs"
+        assert np.array_equal(st["gate"], conv(ref["gate"])), "gadget gate stream differs"
+        assert np.array_equal(st["dense"], conv(ref["dense"][:, : st["rows"]])), "gadget chip dense differs"
+        assert np.array_equal(st["spread"], conv(ref["spread"][:, : st["rows"]])), "gadget chip spread differs"
+        assert rep["violations"] == 0, rep
+        self.stats["gadget_runs"] = self.stats.get("gadget_runs", 0) + 1
+        self.stats["block_cells"] += len(ref["gate"])
+
     # ---------------------------------------------------------------- host delivery
     def host_case(self):
         """hsw_witness_blocks_host: numpy in, numpy out -- the pipelined path (cursor a multiple of the column
@@ -299,7 +367,8 @@ class Fuzzer:
             self.current = None
             try:
                 u = self.rng.random()
-                self.block_case() if u < 0.65 else self.digest_case() if u < 0.95 else self.host_case()
+                (self.block_case() if u < 0.55 else self.digest_case() if u < 0.8 else self.gadget_case() if u < 0.95
+                 else self.host_case())
             except Exception:
                 print("FAILED case:", self.current, file=sys.stderr, flush=True)
                 raise
