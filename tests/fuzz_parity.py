@@ -313,10 +313,10 @@ class Fuzzer:
         self.current = desc
         eng = self.engine(bits, ncols, True)
         cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True)
+        max_rows = None
         try:
             if mont:
                 cfg.set_repr(N.HSW_REPR_MONTGOMERY)
-            max_rows = None
             if columns:
                 max_rows = int(rng.integers(eng.G + 16, 4 * eng.G))
                 desc["max_rows"] = max_rows
@@ -330,8 +330,15 @@ class Fuzzer:
             res = cfg.digest_batch(msgs, pres) if batch else [cfg.digest(m, p) for m, p in zip(msgs, pres)]
             st = cfg.streams()
             rep = cfg.verify()
+            if rng.random() < 0.3:                    # hsw_gadget_download_region: the same image in host memory
+                host = cfg.download_region(pinned=bool(rng.integers(0, 2)))
+                for k in ("gate", "lookup", "dense", "spread"):
+                    assert np.array_equal(host[k], st[k]), "download_region %s differs from the device image" % k
+                self.stats["downloads"] = self.stats.get("downloads", 0) + 1
         finally:
             cfg.close()
+        if nd >= 2 and rng.random() < 0.25:
+            self._seek_split(eng, sizes, msgs, pres, rc, mont, max_rows if columns else None, st, int(rng.integers(1, nd)))
         ref = self.O.digest_cells(msgs, sizes, pres, rc, num_bits_lookup=bits, num_advice_columns=ncols)
         for m, r in zip(msgs, res):
             assert r.output_bytes == hashlib.sha256(m).digest(), "digest differs from SHA-256"
@@ -358,6 +365,49 @@ class Fuzzer:
         self.stats["digest_runs"] += 1
         self.stats["digest_cells"] += len(ref["gate"])
         return desc
+
+    def _seek_split(self, eng, sizes, msgs, pres, rc, mont, max_rows, full, k):
+        """hsw_gadget_seek: gadget A assigns digests [0, k), gadget B seeks to k and assigns the rest; together
+        they must give the image one gadget writes (`full`), each touching only its own cells."""
+        hsw, N = self.hsw, self.N
+        parts = []
+        for first, last in ((0, k), (k, len(msgs))):
+            cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True)
+            try:
+                if mont:
+                    cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+                if max_rows:
+                    cfg.set_columns(max_rows)
+                if first:
+                    cfg.seek(first)
+                res = cfg.digest_batch(msgs[first:last], pres[first:last])
+                assert cfg.verify()["violations"] == 0
+                v = cfg.view()
+                n_gate = int(v.max_rows * v.columns) if max_rows else int(v.gate_capacity)
+
+                def grab(ptr, n_cells):
+                    a = np.zeros((n_cells, 4), dtype=np.uint64)
+                    cfg._ok(cfg.lib.hsw_download(eng.h, a.ctypes.data, ptr, n_cells * 32))
+                    return a
+                parts.append(dict(gate=grab(v.d_gate, n_gate), lookup=grab(v.d_lookup, int(v.lookup_capacity)),
+                                  cells=int(v.gate_cells), lookups=int(v.lookup_cells), res=res))
+            finally:
+                cfg.close()
+        a, b = parts
+        for m, r in zip(msgs[k:], b["res"]):
+            assert r.output_bytes == hashlib.sha256(m).digest()
+        if max_rows:
+            fg = full["gate"].reshape(-1, 4)
+            # the column image is zero-initialised: the two parts are disjoint and their union is the whole
+            assert np.array_equal(a["gate"] | b["gate"], fg), "seek: union of the two gadgets' images differs"
+            assert not (a["gate"].any(axis=1) & b["gate"].any(axis=1)).any(), "seek: the two gadgets overlap"
+        else:
+            cut, end = a["cells"], b["cells"]
+            assert end == len(full["gate"])
+            assert np.array_equal(a["gate"][:cut], full["gate"][:cut]) and np.array_equal(b["gate"][cut:end], full["gate"][cut:end])
+        lc, le = a["lookups"], b["lookups"]
+        assert np.array_equal(a["lookup"][:lc], full["lookup"][:lc]) and np.array_equal(b["lookup"][lc:le], full["lookup"][lc:le])
+        self.stats["seek_splits"] = self.stats.get("seek_splits", 0) + 1
 
     def run(self, seconds=None, iterations=None, log=None):
         t0 = time.time()
