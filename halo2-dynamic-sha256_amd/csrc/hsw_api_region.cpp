@@ -211,7 +211,8 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
         if (descs[i].n_blocks == 0 || descs[i].n_blocks != descs[0].n_blocks ||
             (descs[i].is_input_range_check != 0) != (descs[0].is_input_range_check != 0))
             return set_err(e, HSW_ERR_INVALID_ARG, "one call verifies equally shaped digests (same n_blocks, same range-check setting)");
-        if ((uint64_t)descs[i].num_round != (descs[i].input_len + 9 + 63) / 64 || descs[i].precomputed_round > descs[i].num_round)
+        if ((uint64_t)descs[i].num_round != (descs[i].input_len + 9 + 63) / 64 || descs[i].precomputed_round > descs[i].num_round ||
+            descs[i].num_round - descs[i].precomputed_round > descs[i].n_blocks)       // lib.rs:80-90
             return set_err(e, HSW_ERR_INVALID_ARG, "inconsistent digest descriptor");
     }
     DeviceScope ds(e->device);

@@ -292,18 +292,7 @@ class Fuzzer:
         bits = int(rng.choice([8, 8, 8, 16, 4]))
         ncols = int(rng.choice([2, 2, 1, 3]))
         nd = int(rng.integers(1, 5))
-        equal = rng.random() < 0.4
-        sizes, msgs, pres = [], [], []
-        for i in range(nd):
-            nb = int(rng.choice([1, 2, 3, 4, 8])) if not (equal and sizes) else sizes[0] // 64
-            pre_rounds = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
-            # total padded rounds must satisfy max(pre_rounds, 1) <= num_round <= pre_rounds + nb (lib.rs:89-90)
-            num_round = int(rng.integers(max(pre_rounds, 1), pre_rounds + nb + 1))
-            lo, hi = max(0, 64 * (num_round - 1) - 8), 64 * num_round - 9           # ceil((ln + 9) / 64) == num_round
-            ln = int(rng.integers(lo, hi + 1)) if rng.random() < 0.8 else int(rng.choice([lo, hi]))
-            sizes.append(64 * nb)
-            pres.append(64 * pre_rounds)
-            msgs.append(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+        sizes, msgs, pres = self._random_digests(nd, [1, 2, 3, 4, 8], equal=rng.random() < 0.4)
         rc = bool(rng.integers(0, 2))
         batch = bool(rng.integers(0, 2))
         mont = rng.random() < 0.35

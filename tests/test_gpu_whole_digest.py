@@ -159,6 +159,8 @@ def test_frame_argument_errors(hsw, eng_int, engine_factory):
     assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_UNSUPPORTED
     d.n_blocks, d.input_len, d.num_round = 1, 100, 2                                 # needs 2 blocks, max is 1
     assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0) == N.HSW_ERR_TOO_LARGE
+    rep = N.VerifyReport()                                                            # the verifier refuses it too
+    assert L.hsw_verify_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, 0, C.byref(rep)) == N.HSW_ERR_INVALID_ARG
     d.input_len, d.num_round = 3, 1
     assert L.hsw_witness_frames(eng_int.h, C.byref(d), 1, p, p, p, p, p, None, N.HSW_REPR_COMPACT64) == N.HSW_ERR_UNSUPPORTED
     plain = engine_factory(8, 2)                                                     # not in internals mode
