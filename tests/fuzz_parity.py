@@ -8,6 +8,7 @@ Every iteration draws a point of the cross product the parametrised tests only s
                   FlexGate column packing with a random start row / column height
   gadget streams  Sha256DynamicConfig.digest / digest_batch in random groupings (both chaining sides, zero-copy
                   or staged inputs, reset), canonical / Montgomery
+  chain pre-pass  hsw_sha256_chain around the 64-lane / 256-thread boundaries, FIPS IV or given prefix states
   host delivery   hsw_witness_blocks_host around its 128-block chunking, both cursor alignments, pinned or not
   whole digests   random message lists (lengths, maximum sizes, precomputed prefixes, input range checks,
                   one batch or one call per digest, canonical / Montgomery, linear stream or column image)
@@ -286,6 +287,28 @@ class Fuzzer:
         self.stats["host_runs"] = self.stats.get("host_runs", 0) + 1
         self.stats["block_cells"] += n * (eng.G + 2 * eng.limb_calls)
 
+    # ---------------------------------------------------------------- chain pre-pass
+    def chain_case(self):
+        """hsw_sha256_chain: the plain SHA-256 chain that makes the blocks of a message independent
+        (lib.rs:188,236), one lane per message, from the FIPS IV or from given prefix states (lib.rs:153-160)."""
+        rng, t = self.rng, self.torch
+        nm = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000]))
+        bpm = int(rng.choice([1, 2, 3, 16, 33]))
+        custom = bool(rng.integers(0, 2))
+        self.current = dict(kind="chain", n_messages=nm, blocks_per_message=bpm, custom_init=custom)
+        eng = self.engine(8, 2, False)
+        blocks = rng.integers(0, 256, (nm * bpm, 64), dtype=np.uint8)
+        init = rng.integers(0, 2**32, (nm, 8), dtype=np.uint64).astype(np.uint32) if custom else None
+        pre = eng.sha256_chain(t.from_numpy(blocks).cuda(), nm, bpm,
+                               t.from_numpy(init.view(np.int32)).cuda() if custom else None).cpu().numpy().view(np.uint32)
+        # a handful of messages, chained with the oracle's plain compression (first, last, some in between)
+        for mi in sorted({0, nm - 1, nm // 2, int(rng.integers(0, nm))}):
+            st = init[mi].copy() if custom else self.O.INIT_STATE.copy()
+            for j in range(bpm):
+                assert np.array_equal(pre[mi * bpm + j], st), "pre-state of message %d block %d differs" % (mi, j)
+                st = self.O.plain_compress(st, blocks[mi * bpm + j])
+        self.stats["chain_runs"] = self.stats.get("chain_runs", 0) + 1
+
     # ---------------------------------------------------------------- whole digests
     def digest_case(self):
         rng, N, hsw = self.rng, self.N, self.hsw
@@ -406,8 +429,8 @@ class Fuzzer:
             self.current = None
             try:
                 u = self.rng.random()
-                (self.block_case() if u < 0.55 else self.digest_case() if u < 0.8 else self.gadget_case() if u < 0.95
-                 else self.host_case())
+                (self.block_case() if u < 0.55 else self.digest_case() if u < 0.8 else self.gadget_case() if u < 0.93
+                 else self.host_case() if u < 0.98 else self.chain_case())
             except Exception:
                 print("FAILED case:", self.current, file=sys.stderr, flush=True)
                 raise
