@@ -176,7 +176,6 @@ int hsw_engine_create_ex(int device, void *hip_stream, uint32_t num_bits_lookup,
     hsw_shape shape;
     int rc = hsw_shape_query_ex(num_bits_lookup, num_advice_columns, mode, &shape);
     if (rc != HSW_OK) return rc;
-    if (mode == HSW_MODE_HALO2_INTERNALS && shape.limbs_per_spread > 4) return HSW_ERR_UNSUPPORTED;   // 2- / 1-bit tables: not built
 
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return HSW_ERR_NO_DEVICE;
@@ -338,6 +337,8 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
     }
     if (args->d_lookup && e->mode != HSW_MODE_HALO2_INTERNALS)
         return set_err(e, HSW_ERR_INVALID_ARG, "d_lookup needs an engine created with HSW_MODE_HALO2_INTERNALS");
+    if (e->mode == HSW_MODE_HALO2_INTERNALS && e->limbs > 4 && (flags & HSW_REPR_COMPACT64))
+        return set_err(e, HSW_ERR_UNSUPPORTED, "internals mode with a 2- or 1-bit spread table: 32-byte cells only (no HSW_REPR_COMPACT64)");
     if (args->d_lookup && ((uintptr_t)args->d_lookup & 15u))
         return set_err(e, HSW_ERR_INVALID_ARG, "lookup buffer not 16-byte aligned");
     if (args->pack && args->pack->n_breaks > HSW_MAX_BREAKS)

@@ -1080,12 +1080,28 @@ static hipError_t launch_expand_LTR(const ExpandParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// halo2-base internals for the 2- and 1-bit tables (8 / 16 limbs per spread): these kernels compile for ~30 s
+// each, so they live in translation units of their own (hsw_expand_l8_rc.hip, hsw_expand_l16_rc.hip) and only
+// the two 32-byte representations are built (no HSW_REPR_COMPACT64).
+template <int L>
+hipError_t launch_expand_L_internals_wide(const ExpandParams &p, hipStream_t stream) {
+    if (p.flags & (HSW_K_COMPACT | HSW_K_SPLIT)) return hipErrorInvalidValue;
+    if (p.parts * 64u < 64u) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(p.n_blocks * p.parts)), block(64);
+    if (p.flags & HSW_K_MONTGOMERY)
+        hipLaunchKernelGGL((hsw_expand_kernel<L, 32, 64, 1, true>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((hsw_expand_kernel<L, 32, 64, 0, true>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+extern template hipError_t launch_expand_L_internals_wide<8>(const ExpandParams &, hipStream_t);
+extern template hipError_t launch_expand_L_internals_wide<16>(const ExpandParams &, hipStream_t);
+
 template <int L>
 hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
     if (p.flags & HSW_K_INTERNALS) {
-        // halo2-base internals (A3): table widths 16, 8 and 4 bits (1, 2, 4 limbs per spread; the 2- and 1-bit
-        // tables would triple the build time for no known user); the wider tiles for the reference's 8-bit table only
+        // halo2-base internals (A3): the wider tiles for the reference's 8-bit table only
         if constexpr (L == 2) {
             switch (tile) {
                 case 64: return launch_expand_LTR<L, 64, 32, true>(p, stream);
@@ -1093,7 +1109,7 @@ hipError_t launch_expand_L(const ExpandParams &p, int tile, hipStream_t stream) 
                 default: return launch_expand_LTR<L, 32, 64, true>(p, stream);
             }
         } else if constexpr (L <= 4) return launch_expand_LTR<L, 32, 64, true>(p, stream);
-        else return hipErrorInvalidValue;
+        else return launch_expand_L_internals_wide<L>(p, stream);
     }
     switch (tile) {
         case 6416: if constexpr (L == 2) return launch_expand_LTR<L, 64, 16, false>(p, stream); else return hipErrorInvalidValue;

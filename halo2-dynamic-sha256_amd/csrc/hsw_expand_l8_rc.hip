@@ -1,0 +1,5 @@
+// halo2-internals expansion kernels for 8 limbs per spread (num_bits_lookup = 2); see hsw_expand.hpp.
+#include "hsw_expand.hpp"
+namespace hsw {
+template hipError_t launch_expand_L_internals_wide<8>(const ExpandParams &, hipStream_t);
+}

@@ -117,7 +117,8 @@ typedef struct hsw_shape {
  * block => G = 69,348) -- and make the lookup-advice column stream available
  * (what RangeConfig::finalize copies, lib.rs:469: 3,184 cells per block).
  * These follow halo2-lib v0.2.x (DESIGN.md assumption A3); the fork the
- * reference pins is not in its tree, so A3 is unpinned.  Spread tables of 16, 8 or 4 bits. */
+ * reference pins is not in its tree, so A3 is unpinned.  Every table width; with the 2- and 1-bit
+ * tables only 32-byte cells (canonical / Montgomery), not HSW_REPR_COMPACT64. */
 #define HSW_MODE_HALO2_INTERNALS  1u
 
 /* Fill *out for the given SpreadConfig parameters.  Pure host arithmetic. */

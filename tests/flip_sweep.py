@@ -148,7 +148,7 @@ if __name__ == "__main__":
     ncols = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     mont = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
     limb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    internals = bits in (16, 8, 4) and (bool(int(sys.argv[5])) if len(sys.argv) > 5 else True)
+    internals = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
     m = sweep(bits, ncols, mont, internals=internals, limb=limb, log=sys.stdout)
     if bits == 8 and ncols == 2 and internals:
         m.update(sweep_frames(mont=mont, limb=limb, log=sys.stdout))

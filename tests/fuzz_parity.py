@@ -81,7 +81,7 @@ class Fuzzer:
     def block_case(self):
         rng, N, t = self.rng, self.N, self.torch
         internals = bool(rng.integers(0, 2))
-        bits = int(rng.choice([16, 8, 4] if internals else [16, 8, 8, 4, 2, 1]))
+        bits = int(rng.choice([16, 8, 8, 4, 2, 1]))
         ncols = int(rng.integers(1, 7))
         n = int(rng.choice([1, 2, 3, 5, 8, 13, 31, 32, 33, 40]))
         if bits <= 2:
@@ -312,7 +312,7 @@ class Fuzzer:
     # ---------------------------------------------------------------- whole digests
     def digest_case(self):
         rng, N, hsw = self.rng, self.N, self.hsw
-        bits = int(rng.choice([8, 8, 8, 16, 4]))
+        bits = int(rng.choice([8, 8, 8, 16, 4, 2]))
         ncols = int(rng.choice([2, 2, 1, 3]))
         nd = int(rng.integers(1, 5))
         sizes, msgs, pres = self._random_digests(nd, [1, 2, 3, 4, 8], equal=rng.random() < 0.4)

@@ -181,10 +181,10 @@ def test_packing_combined_with_other_representations(hsw, oracle, eng_int, flags
     assert (flat[mask] == np.uint64(2**64 - 1)).all()
 
 
-@pytest.mark.parametrize("bits,ncols", [(16, 2), (4, 2), (4, 3)])
+@pytest.mark.parametrize("bits,ncols", [(16, 2), (4, 2), (4, 3), (2, 2), (1, 3)])
 def test_internals_other_table_widths(hsw, oracle, bits, ncols):
-    """Internals mode (range_check rows + lookup column), digest frames and on-device verification for the
-    16- and 4-bit spread tables too."""
+    """Internals mode (range_check rows + lookup column), digest frames and on-device verification for every
+    other table width the reference admits (16 % num_bits_lookup == 0)."""
     import hashlib
     import torch
     N = hsw._native
@@ -213,5 +213,12 @@ def test_internals_other_table_widths(hsw, oracle, bits, ncols):
             assert r.output_bytes == hashlib.sha256(m).digest()
     finally:
         eng.close()
-    with pytest.raises(hsw.HswError):                         # the 2- and 1-bit tables are not built in this mode
-        hsw.WitnessEngine(0, 2, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+    if bits <= 2:                                             # ... in 32-byte cells; the compact form is not built there
+        eng = hsw.WitnessEngine(0, bits, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
+        with pytest.raises(hsw.HswError) as ei:
+            eng.witness_blocks(tb, tp, flags=N.HSW_REPR_COMPACT64)
+        assert ei.value.status == N.HSW_ERR_UNSUPPORTED
+        out = eng.witness_blocks(tb, tp, cursor0=5, flags=N.HSW_REPR_MONTGOMERY)
+        eng.synchronize()
+        assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), oracle.to_montgomery(ref["gate"]))
+        eng.close()
