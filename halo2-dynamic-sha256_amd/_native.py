@@ -142,7 +142,7 @@ def build(force=False):
     """Compile libhsw.so for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
-    subprocess.check_call(["make", "-C", CSRC, "-s", "-j6"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libhsw.so was not produced by csrc/Makefile")
     return LIB_PATH

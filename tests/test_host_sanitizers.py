@@ -17,7 +17,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
     kernels = [os.path.join(CSRC, f) for f in ("hsw_kernels.o", "hsw_frame.o", "hsw_verify.o", "hsw_expand_l1.o", "hsw_expand_l2.o",
                                                "hsw_expand_l4.o", "hsw_expand_l8.o", "hsw_expand_l16.o", "hsw_expand_l8_rc.o", "hsw_expand_l16_rc.o")]
     if not all(os.path.exists(k) for k in kernels):
-        subprocess.check_call(["make", "-C", CSRC, "-s", "-j6"])
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     exe = str(tmp_path / "host_sanity")
     san = ["-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer"]
