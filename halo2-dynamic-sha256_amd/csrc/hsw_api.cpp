@@ -263,6 +263,11 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
         e->verify_slices = (int)value;
         return HSW_OK;
     }
+    if (std::strcmp(name, "chunk_blocks") == 0) {      // blocks per launch of a long batch; tests shrink it to reach that loop
+        if (value < 1 || value > (1 << 20)) return set_err(e, HSW_ERR_INVALID_ARG, "chunk_blocks must be 1 .. 2^20");
+        e->chunk_blocks = (size_t)value;
+        return HSW_OK;
+    }
     if (std::strcmp(name, "split") == 0) {
         if (value < -1 || value > 1) return set_err(e, HSW_ERR_INVALID_ARG, "split must be -1 (auto), 0 or 1");
         e->split = (int)value;
@@ -361,7 +366,8 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
 
     // One launch covers up to 2^20 blocks (2.5 TB of cells would be far past
     // HBM anyway); longer batches are issued as consecutive launches.
-    const size_t CHUNK = (size_t)1 << 20;
+    // (a framed call is always one launch: n_blocks <= 2^20 was checked above; the option is a test knob)
+    const size_t CHUNK = args->frame_every ? ((size_t)1 << 20) : e->chunk_blocks;
     const size_t G = e->shape.gate_cells_per_block;
     hipError_t he;
     if (e->timing) {

@@ -22,6 +22,7 @@ struct hsw_engine {
     int parts = 0;             // waves per block; 0 = choose from the batch size
     int split = -1;            // one phase per wave (32 waves per block): -1 = for tiny batches, 0 = never, 1 = always
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
+    size_t chunk_blocks = (size_t)1 << 20;   // blocks per launch (longer batches are consecutive launches)
     uint32_t mode = HSW_MODE_DEFAULT;
     bool timing = false;
     bool timed = false;        // ev0/ev1 bracket a launch

@@ -534,7 +534,8 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
  * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
  * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": one phase
  * program per wave, 32 waves per block -- -1 = for batches of <= 32 blocks (default), 0 = never,
- * 1 = always. */
+ * 1 = always.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
+ * "chunk_blocks": blocks per kernel launch of a long batch (default and maximum 2^20; a test knob). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 
 const char *hsw_strerror(int status);

@@ -93,8 +93,9 @@ class Fuzzer:
         split = int(rng.choice([-1, -1, 0, 1]))
         shift = int(rng.choice([0, 0, 1, 2, 3]))
         pack = rng.random() < 0.4
+        chunk = int(rng.choice([1 << 20, 1 << 20, 1, 3, 5]))      # blocks per launch: reach the multi-launch loop
         desc = dict(kind="blocks", internals=internals, bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags,
-                    tile=tile, parts=parts, split=split, shift=shift, pack=pack)
+                    tile=tile, parts=parts, split=split, shift=shift, pack=pack, chunk=chunk)
         self.current = desc
         eng = self.engine(bits, ncols, internals)
         G, LK = eng.G, eng.lookup_cells
@@ -135,6 +136,7 @@ class Fuzzer:
         eng.set_option("tile", tile)
         eng.set_option("parts", parts)
         eng.set_option("split", split)
+        eng.set_option("chunk_blocks", chunk)
         try:
             rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
             if rc == N.HSW_ERR_UNSUPPORTED:      # e.g. more than two column breaks inside one block
@@ -146,6 +148,7 @@ class Fuzzer:
             eng.set_option("tile", 0)
             eng.set_option("parts", 0)
             eng.set_option("split", -1)
+            eng.set_option("chunk_blocks", 1 << 20)
         ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=cursor0)
         eg, ed, es, el = self._expected(ref, eng, n, flags, internals)
         flat = big.cpu().numpy().view(np.uint64)

@@ -374,6 +374,27 @@ def test_pipelined_host_delivery_leaves_the_next_calls_cells_alone(engine_factor
     assert np.array_equal(got["gate"], oracle.to_montgomery(ref["gate"]))
 
 
+@pytest.mark.parametrize("chunk", [1, 3])
+def test_long_batches_split_into_launches(engine_factory, oracle, hsw, chunk):
+    """Batches longer than 2^20 blocks are issued as consecutive launches (chip cursor, row offsets and
+    column breaks re-based per launch); the "chunk_blocks" option shrinks that limit so the loop runs here."""
+    eng = engine_factory(8, 3)
+    eng.set_option("chunk_blocks", chunk)
+    try:
+        blocks, pre = _rand_inputs(8, 4242)
+        ref = oracle.Oracle(8, 3, check=True).witness_blocks(blocks, pre, cursor0=5)
+        for flags, conv in ((0, lambda x: x), (hsw.HSW_REPR_MONTGOMERY, oracle.to_montgomery)):
+            got = _run_gpu(eng, blocks, pre, cursor0=5, flags=flags)
+            assert np.array_equal(got["gate"].view(np.uint64), conv(ref["gate"]))
+            assert np.array_equal(got["dense"].view(np.uint64), conv(ref["dense"]))
+            assert np.array_equal(got["spread"].view(np.uint64), conv(ref["spread"]))
+            assert np.array_equal(got["next_states"].view(np.uint32), ref["next_states"])
+    finally:
+        eng.set_option("chunk_blocks", 1 << 20)
+    with pytest.raises(hsw.HswError):
+        eng.set_option("chunk_blocks", 0)
+
+
 def test_hip_graph_capture_and_replay(hsw, oracle):
     """The launch path does no allocation / synchronization, so chain + expand can
     be captured into a HIP graph and replayed on new inputs (launch-bound small
