@@ -7,12 +7,10 @@
 // with the block bytes and the pre-state entering only through the external cells they are
 // copy-constrained to.  The structure is the product's own (csrc/hsw_structure.hpp); no value is
 // recomputed from the inputs, so a stream that passes is the witness of its inputs by the uniqueness
-// argument of SURVEY 8c.  Canonical 32-byte cells.  One pass over the gate rows checks the row equation and,
-// on the same four loads, the constants and copies among the row's cells.  ~3.8 ms for 4,096 blocks (2.2x
-// the time it took to write them): latency-bound on the chain structure -> cell -> copy source, not on
-// bytes -- staging the stream through LDS in 1,024-cell windows made no difference (94 % of the copy
-// sources are within 1,024 cells of their copy).  `slices` workgroups may share a block: small batches
-// are sliced to fill the chip.
+// argument of SURVEY 8c.  One pass over the gate rows (four lanes per row, one cell each) checks the row
+// equation and, on the same loads, the constants and copies among the row's cells; then the assert_equal
+// pairs, range bounds, chip ties and lookup copies.  ~3.0 ms for 4,096 blocks (1.8x the time it took to
+// write them).  `slices` workgroups may share a block: small batches are sliced to fill the chip.
 #include "hsw_expand.hpp"
 #include "hsw_frame.hpp"
 #include "hsw_verify.h"
@@ -32,7 +30,7 @@ DEV Cell load_cell(const uint4 *gate, u64 idx) {
 }
 // HSW_REPR_MONTGOMERY streams are checked in the canonical domain: every loaded cell m = x * 2^256 mod p is
 // reduced to x on the fly (one Montgomery reduction) wherever its VALUE is needed -- gate equation, constants, ranges;
-// copies of stream cells are compared as stored.  4.0 ms per 4,096 blocks against 3.9 ms canonical.
+// copies of stream cells are compared as stored.  3.1-3.3 ms per 4,096 blocks against 3.0 ms canonical.
 DEV Cell from_mont(const Cell &a) {
     const u64 P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
     const u64 INV = 0xc2e1f593efffffffull;                       // -p^-1 mod 2^64
@@ -173,40 +171,62 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
     //    rows with a full-width cell are the negations of ch: [a, p-a, 1, 0] and [M, p-a, 1, M-a]
     //    (compression.rs:320-335)
     //    Copies of stream cells are compared as stored (raw to raw: equal values have equal encodings, and a
-    //    Montgomery stream needs no reduction for them); the source loads of a row are issued together, before the
-    //    first of them is used, so that their latencies overlap.
+    //    Montgomery stream needs no reduction for them).
+    //    Work split: FOUR lanes per gate row, one per cell.  A quad then reads its row as 128 contiguous bytes
+    //    and a wave instruction covers 16 rows in 16 lines -- with one lane per row every load instruction
+    //    touched 64 different lines, 16 bytes of each, and the L1 had to keep them all until the row's eighth
+    //    load (measured: 3.9 L2 requests per line of the stream, the kernel stalled on them 75 % of the time).
+    //    Each lane checks its own cell (constant / copy: one source load per lane, all in flight together);
+    //    the row equation gets the other three cells' low limbs by DPP quad broadcasts.
     auto raw_cell = [&](u64 idx) -> Cell { return load_cell(gate, packed ? place(p, idx) : idx); };
-    for (u32 r = tid; r < p.n_rows; r += nt) {
-        const u32 c = p.gate_rows[r];
-        Cell raw[4], x[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) raw[j] = raw_cell(g0 + c + j);
-        uint8_t k[4];
-        int64_t rf[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { k[j] = p.kind[c + j]; rf[j] = p.ref[c + j]; }
-        Cell w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { if (k[j] == 2 && rf[j] >= 0) w[j] = raw_cell(g0 + (u64)rf[j]); else w[j] = raw[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; j++) { if constexpr (MONT) x[j] = from_mont(raw[j]); else x[j] = raw[j]; }
-        bool ok;
-        if (narrow(x[0]) && narrow(x[1]) && narrow(x[2]) && narrow(x[3])) {
-            const unsigned __int128 s = (unsigned __int128)x[1].l[0] * x[2].l[0] + x[0].l[0];
-            ok = (u64)(s >> 64) == 0 && (u64)s == x[3].l[0];
-        } else {
-            const u64 P0 = 0x43e1f593f0000001ull, P1 = 0x2833e84879b97091ull, P2 = 0xb85045b68181585dull, P3 = 0x30644e72e131a029ull;
-            const u64 a = P0 - x[1].l[0];                                    // x1 = p - a
-            ok = narrow(x[0]) && narrow(x[3]) && narrow(x[2]) && x[2].l[0] == 1 && x[1].l[1] == P1 && x[1].l[2] == P2 &&
-                 x[1].l[3] == P3 && a >= 1 && a <= 0x55555555ull && x[0].l[0] >= a && x[0].l[0] - a == x[3].l[0];
+    auto quad64 = [](u64 v, int q) -> u64 {            // lane q of the quad's value, in every lane of the quad
+        const int lo = (int)(u32)v, hi = (int)(u32)(v >> 32);
+        int rl, rh;
+        switch (q) {
+            case 0: rl = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); rh = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); break;
+            case 1: rl = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true); rh = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true); break;
+            case 2: rl = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true); rh = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true); break;
+            default: rl = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true); rh = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true); break;
         }
-        if (!ok) fail(VERIFY_GATE_ROW, c);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (k[j] == 1) { if (!same(x[j], small((u64)rf[j]))) fail(VERIFY_CONSTANT, c + j); }
-            else if (k[j] == 2) {
-                if (rf[j] >= 0) { if (!same(raw[j], w[j])) fail(VERIFY_COPY, c + j); }
-                else { bool known; const Cell e = cell_of(rf[j], known); if (known && !same(x[j], e)) fail(VERIFY_COPY, c + j); }
+        return (u64)(u32)rl | ((u64)(u32)rh << 32);
+    };
+    const u32 j4 = threadIdx.x & 3u;                   // this lane's cell of the row
+    const u32 slot = tid >> 2, nslots = nt >> 2;       // row slots of the launch slice (nt is a multiple of 4)
+    for (u32 rb = 0; rb < p.n_rows; rb += nslots) {    // the same trip count in every lane: DPP needs whole quads
+        const u32 r = rb + slot;
+        const bool act = r < p.n_rows;
+        const u32 c = p.gate_rows[act ? r : 0u];
+        const u32 cell = c + j4;
+        const Cell raw = raw_cell(g0 + cell);
+        const uint8_t k = p.kind[cell];
+        const int64_t rf = p.ref[cell];
+        Cell w = raw;
+        if (act && k == 2 && rf >= 0) w = raw_cell(g0 + (u64)rf);
+        Cell x;
+        if constexpr (MONT) x = from_mont(raw); else x = raw;
+        // ---- the row: x0 + x1*x2 = x3
+        const u64 l0 = quad64(x.l[0], 0), l1 = quad64(x.l[0], 1), l2 = quad64(x.l[0], 2), l3 = quad64(x.l[0], 3);
+        const u64 up = x.l[1] | x.l[2] | x.l[3];        // 0 <=> this cell is narrow
+        const u64 up0 = quad64(up, 0), up1 = quad64(up, 1), up2 = quad64(up, 2), up3 = quad64(up, 3);
+        bool ok;
+        if ((up0 | up1 | up2 | up3) == 0) {
+            const unsigned __int128 s128 = (unsigned __int128)l1 * l2 + l0;
+            ok = (u64)(s128 >> 64) == 0 && (u64)s128 == l3;
+        } else {
+            // the only rows with a full-width cell: [a, p-a, 1, 0] and [M, p-a, 1, M-a] (compression.rs:320-335)
+            const u64 P0 = 0x43e1f593f0000001ull, P1 = 0x2833e84879b97091ull, P2 = 0xb85045b68181585dull, P3 = 0x30644e72e131a029ull;
+            const u64 x11 = quad64(x.l[1], 1), x12 = quad64(x.l[2], 1), x13 = quad64(x.l[3], 1);
+            const u64 a = P0 - l1;                                            // x1 = p - a
+            ok = (up0 | up2 | up3) == 0 && l2 == 1 && x11 == P1 && x12 == P2 && x13 == P3 && a >= 1 && a <= 0x55555555ull &&
+                 l0 >= a && l0 - a == l3;
+        }
+        if (act && !ok && j4 == 0) fail(VERIFY_GATE_ROW, c);
+        // ---- this lane's cell
+        if (act) {
+            if (k == 1) { if (!same(x, small((u64)rf))) fail(VERIFY_CONSTANT, cell); }
+            else if (k == 2) {
+                if (rf >= 0) { if (!same(raw, w)) fail(VERIFY_COPY, cell); }
+                else { bool known; const Cell e = cell_of(rf, known); if (known && !same(x, e)) fail(VERIFY_COPY, cell); }
             }
         }
     }
@@ -224,19 +244,34 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         if (known && !(narrow(v) && (bits >= 64 || (v.l[0] >> bits) == 0))) fail(VERIFY_RANGE, (u32)p.range[2 * i]);
     }
     // 5. spread chip: limb call n of this block is absolute call N = cursor0 + blk*LC + n -> column N % ncols,
-    //    row N / ncols (spread.rs:202-231); the cells are tied to gate cells and form a row of the spread table
+    //    row N / ncols (spread.rs:202-231); the cells are tied to gate cells and form a row of the spread table.
+    //    Two lanes per limb call -- the dense pair and the spread pair -- each with one chip cell and one gate cell
+    //    to load (compared as stored); the table relation takes the partner's low limb by a DPP swap.
     if (p.chip_dense) {
         const uint4 *cd = reinterpret_cast<const uint4 *>(p.chip_dense), *csp = reinterpret_cast<const uint4 *>(p.chip_spread);
         const u64 row0 = p.cursor0 / p.ncols;
-        for (u32 n = tid; n < p.limb_calls; n += nt) {
-            const u64 N = p.cursor0 + blk * (u64)p.limb_calls + n;
+        const u32 half = threadIdx.x & 1u;                                    // 0: dense, 1: spread
+        auto swap32 = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };   // quad_perm [1,0,3,2]
+        for (u32 nb = 0; nb < p.limb_calls; nb += nt >> 1) {                  // the same trip count in every lane
+            const u32 n = nb + (tid >> 1);
+            const bool act = n < p.limb_calls;
+            const u32 nn = act ? n : 0u;
+            const u64 N = p.cursor0 + blk * (u64)p.limb_calls + nn;
             const u64 at = (N % p.ncols) * (u64)p.chip_col_stride + (N / p.ncols - row0);
-            const Cell d = load_value<MONT>(cd, at), sp = load_value<MONT>(csp, at);
-            bool k1, k2;
-            const Cell gd = cell_of(p.chip[2 * n], k1), gs = cell_of(p.chip[2 * n + 1], k2);
-            const bool ok = same(d, gd) && same(sp, gs) && narrow(d) && narrow(sp) && d.l[0] < (1ull << p.num_bits_lookup) &&
-                            (u64)spread16((u32)d.l[0]) == sp.l[0];
-            if (!ok) fail(VERIFY_CHIP, (u32)p.chip[2 * n + 1]);
+            const Cell rv = load_cell(half ? csp : cd, at);
+            const int64_t id = p.chip[2 * nn + half];
+            bool tied;
+            Cell v;
+            if constexpr (MONT) v = from_mont(rv); else v = rv;
+            if (id >= 0) tied = same(rv, raw_cell(g0 + (u64)id));
+            else { bool known; const Cell e = cell_of(id, known); tied = !known || same(v, e); }
+            const u32 lo = (u32)v.l[0], hi = (u32)(v.l[0] >> 32);
+            const u32 plo = swap32(lo), phi = swap32(hi);                     // the partner's low limb
+            bool ok = tied && narrow(v);
+            if (half) ok = ok && phi == 0 && (u64)spread16(plo) == v.l[0];    // (dense, spread) is a row of the table
+            else ok = ok && v.l[0] < (1ull << p.num_bits_lookup);
+            const u32 both = (ok ? 1u : 0u) & swap32(ok ? 1u : 0u);
+            if (act && half == 0 && !both) fail(VERIFY_CHIP, (u32)p.chip[2 * nn + 1]);
         }
     }
     // 6. lookup-advice column: entry j copies its source cell and is a 16-bit range-table entry
