@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 (rocpd .db) outputs into the small summaries kept under profiles/.
 usage: profile_extract.py stats <db> <out.csv>
+       profile_extract.py stats_by_grid <db> <out.csv> [min grid]   (one line per kernel AND grid size: separates
+                                                                     the 4,096-block launches from the small ones)
        profile_extract.py traffic <write_db> <fetch_db> <out.json> <kernel substring> <algorithmic bytes per launch>"""
 import csv, json, sqlite3, sys
 
@@ -15,6 +17,17 @@ def stats(db, out):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 3), r[4], r[5]])
+
+
+def stats_by_grid(db, out, min_grid=0):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, grid_x, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       "from kernels where grid_x >= ? group by name, grid_x order by 4 desc", (min_grid,)).fetchall()
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "GridSize", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], r[3], round(r[4], 1), r[5], r[6]])
 
 
 def counter(db, name, kernel):
@@ -44,5 +57,7 @@ def traffic(wdb, rdb, out, kernel, alg):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats_by_grid":
+        stats_by_grid(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]))
