@@ -277,11 +277,12 @@ class Fuzzer:
             cursor0 -= cursor0 % ncols
         flags = int(rng.choice([0, N.HSW_REPR_MONTGOMERY, N.HSW_REPR_COMPACT64]))
         pinned = bool(rng.integers(0, 2))
-        self.current = dict(kind="host", bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags, pinned=pinned)
+        register = (not pinned) and bool(rng.integers(0, 2))      # HSW_HOST_REGISTER: pin the caller's pageable buffers in place
+        self.current = dict(kind="host", bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags, pinned=pinned, register=register)
         eng = self.engine(bits, ncols, False)
         blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
         pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
-        got = eng.witness_blocks_host(blocks, pre, cursor0=cursor0, flags=flags, pinned=pinned)
+        got = eng.witness_blocks_host(blocks, pre, cursor0=cursor0, flags=flags | (N.HSW_HOST_REGISTER if register else 0), pinned=pinned)
         ref = self.O.Oracle(bits, ncols, check=False).witness_blocks(blocks, pre, cursor0=cursor0)
         eg, ed, es, _ = self._expected(ref, eng, n, flags, False)
         assert np.array_equal(got["gate"], eg), "host gate stream differs"
