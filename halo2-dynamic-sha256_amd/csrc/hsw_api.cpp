@@ -564,13 +564,42 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         e->slot_rows = ch_rows;
     }
     const size_t rows_total = (size_t)hsw_chip_rows(&e->shape, cursor0, n_blocks);
-    bool pinned_gate = false, pinned_cd = false, pinned_cs = false;
-    if (pin) {   // pin the caller's buffers in place so the DMA engines can write them directly
-        if (want_gate) pinned_gate = hipHostRegister(gate, n_blocks * G * cb, hipHostRegisterDefault) == hipSuccess;
-        if (want_chip) {
-            const size_t span = ((ncols - 1) * chip_col_stride + rows_total) * cb;
-            pinned_cd = hipHostRegister(chip_dense, span, hipHostRegisterDefault) == hipSuccess;
-            pinned_cs = hipHostRegister(chip_spread, span, hipHostRegisterDefault) == hipSuccess;
+    void *reg_gate = nullptr, *reg_cd = nullptr, *reg_cs = nullptr;      // what hipHostRegister was given
+    if (pin) {
+        // Pin the caller's output buffers in place so that the copies write them directly.  hipHostRegister
+        // works on whole pages, and the runtime takes any copy that STARTS in a registered page for a copy to
+        // pinned memory -- all of it, also the part past the registered range (a GPU memory fault, found by
+        // the fuzzer with two small chip arrays that shared a heap page).  So a buffer is registered only when
+        // no other host buffer of this call touches its pages, and only from 1 MiB up (malloc serves those by
+        // mmap, so the edge pages hold nothing else); all of them or none.
+        const uintptr_t PAGE = 4096;
+        struct Range { uintptr_t lo, hi; bool candidate; void **slot; };
+        auto pages = [&](const void *ptr, size_t bytes, bool cand, void **slot) -> Range {
+            return Range{(uintptr_t)ptr & ~(PAGE - 1), ((uintptr_t)ptr + bytes + PAGE - 1) & ~(PAGE - 1), cand, slot};
+        };
+        const size_t MIN_BYTES = (size_t)1 << 20;
+        const size_t gate_bytes = want_gate ? n_blocks * G * cb : 0;
+        const size_t span = want_chip ? ((ncols - 1) * chip_col_stride + rows_total) * cb : 0;
+        Range r[6];
+        int nr = 0;
+        if (gate_bytes) r[nr++] = pages(gate, gate_bytes, gate_bytes >= MIN_BYTES, &reg_gate);
+        if (span) { r[nr++] = pages(chip_dense, span, span >= MIN_BYTES, &reg_cd); r[nr++] = pages(chip_spread, span, span >= MIN_BYTES, &reg_cs); }
+        r[nr++] = pages(blocks, n_blocks * 64, false, nullptr);
+        r[nr++] = pages(pre_states, n_blocks * 32, false, nullptr);
+        if (next_states) r[nr++] = pages(next_states, n_blocks * 32, false, nullptr);
+        bool safe = true;
+        for (int i = 0; i < nr && safe; i++)
+            for (int j = 0; j < nr && safe; j++)
+                if (i != j && r[i].candidate && r[i].lo < r[j].hi && r[j].lo < r[i].hi) safe = false;
+        if (safe) {
+            for (int i = 0; i < nr && safe; i++)
+                if (r[i].candidate) {
+                    if (hipHostRegister((void *)r[i].lo, r[i].hi - r[i].lo, hipHostRegisterDefault) == hipSuccess) *r[i].slot = (void *)r[i].lo;
+                    else safe = false;
+                }
+            if (!safe)      // all or none
+                for (int i = 0; i < nr; i++)
+                    if (r[i].candidate && *r[i].slot) { (void)hipHostUnregister(*r[i].slot); *r[i].slot = nullptr; }
         }
         (void)hipGetLastError();
     }
@@ -620,9 +649,9 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         if ((he = hipStreamSynchronize(e->copy_stream)) != hipSuccess) { fail("sync copy stream"); break; }
     } while (0);
     if (rc != HSW_OK) { (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->copy_stream); }
-    if (pinned_gate) (void)hipHostUnregister(gate);
-    if (pinned_cd) (void)hipHostUnregister(chip_dense);
-    if (pinned_cs) (void)hipHostUnregister(chip_spread);
+    if (reg_gate) (void)hipHostUnregister(reg_gate);
+    if (reg_cd) (void)hipHostUnregister(reg_cd);
+    if (reg_cs) (void)hipHostUnregister(reg_cs);
     (void)hipFree(d_blocks); (void)hipFree(d_pre); (void)hipFree(d_next);
     return rc;
 }

@@ -73,7 +73,10 @@ extern "C" {
 #define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
 
 #define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only: pin the caller's output buffers
-                                      (hipHostRegister) for the duration of the call */
+                                      (hipHostRegister) for the duration of the call.  Registration is by
+                                      whole pages, so only buffers of at least 1 MiB whose pages no other
+                                      host buffer of the call touches are pinned, all of them or none;
+                                      otherwise the call proceeds with ordinary pageable copies. */
 
 #define HSW_CELL_BYTES         32u
 

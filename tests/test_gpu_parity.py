@@ -395,6 +395,25 @@ def test_long_batches_split_into_launches(engine_factory, oracle, hsw, chunk):
         eng.set_option("chunk_blocks", 0)
 
 
+def test_host_register_with_small_heap_buffers(engine_factory, oracle, hsw):
+    """HSW_HOST_REGISTER on outputs that are too small to own their pages (numpy takes them from the malloc
+    heap, where they share pages with each other and with the inputs): registering them made the runtime
+    treat neighbouring buffers as pinned and write past the registered range -- a GPU memory fault the fuzzer
+    ran into.  Such buffers are now left pageable; the result must simply be right."""
+    N = hsw._native
+    eng = engine_factory(8, 3)
+    blocks, pre = _rand_inputs(1, 99)
+    for flags in (N.HSW_REPR_COMPACT64, 0):
+        got = eng.witness_blocks_host(blocks, pre, cursor0=0, flags=flags | N.HSW_HOST_REGISTER, pinned=False)
+        ref = oracle.Oracle(8, 3, check=False).witness_blocks(blocks, pre, cursor0=0)
+        if flags:
+            eg, ed, es = _compact_expected(oracle, hsw, ref, eng.shape, 1)
+        else:
+            eg, ed, es = ref["gate"], ref["dense"], ref["spread"]
+        assert np.array_equal(got["gate"], eg) and np.array_equal(got["dense"], ed) and np.array_equal(got["spread"], es)
+        assert np.array_equal(got["next_states"], ref["next_states"])
+
+
 def test_hip_graph_capture_and_replay(hsw, oracle):
     """The launch path does no allocation / synchronization, so chain + expand can
     be captured into a HIP graph and replayed on new inputs (launch-bound small
