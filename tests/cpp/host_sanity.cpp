@@ -45,6 +45,8 @@ int main() {
         hsw_frame_shape fs;
         CHECK(hsw_frame_query(&sd, 64, 0, &fs) == HSW_ERR_INVALID_ARG);      // frames are halo2-base internals
         CHECK(hsw_frame_query(&si, 100, 0, &fs) == HSW_ERR_SHAPE);
+        CHECK(hsw_frame_query(&si, ((size_t)1 << 32) + 64, 0, &fs) == HSW_ERR_TOO_LARGE);   // a frame counts its blocks in 32 bits
+        CHECK(hsw_frame_query(&si, (size_t)1 << 32, 1, &fs) == HSW_OK && fs.n_blocks == ((uint64_t)1 << 26));
         for (size_t maxb : {64u, 128u, 1024u}) {
             for (int rc = 0; rc < 2; rc++) {
                 CHECK(hsw_frame_query(&si, maxb, rc, &fs) == HSW_OK);
