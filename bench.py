@@ -11,14 +11,19 @@ synthetic single-block messages that is already resident in HBM.
 
   N=1 workload  BASELINE.json configs[2]: 4,096 independent single-block
                 (55-byte) messages, seed 0xC3 -- the configuration the
-                metric's "achieved HBM GB/s" is quoted on (configs[1], one
-                16-block message, is 38 MB of output: launch-latency bound; it
-                is timed too and reported under "extra").
-  N>1           every rank generates its own 4,096 messages (weak scaling, no
-                data-path collective: messages are independent).  The RCCL
-                all-gather of witness columns that north_star also asks for is
-                timed separately on a bounded shard and reported under
-                "extra.allgather" -- it never enters `value`.
+                metric's "achieved HBM GB/s" is quoted on.  The reference's own
+                bench workload (benches/digest.rs: one 56-byte message, 16
+                blocks, 9 advice columns; configs[0]) and configs[1] (one
+                16-block message) are latency-bound launches of 38 MB: they are
+                timed too, each with its own cpu_baseline and roofline
+                fraction, under "extra".
+  N>1           `python bench.py --gpus N` starts N ranks itself (one fresh
+                process per GPU, RCCL over xGMI) unless it already runs under
+                torch.distributed.run (WORLD_SIZE set).  Every rank generates
+                its own 4,096 messages (weak scaling, no data-path collective:
+                messages are independent).  The RCCL all-gather of witness
+                columns that north_star also asks for is timed separately on a
+                bounded shard ("extra.multi_gpu") -- it never enters `value`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,6 +31,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+IV = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+               0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
 
 
 def sha_pad_single_block(msgs55):
@@ -92,7 +101,6 @@ def cpu_baseline(blocks, pre, cpu_seconds_target=16.0):
     the same workload: every usable host core expands the same kind of
     single-block messages into its own stream buffers (streams written, checks
     off), about `cpu_seconds_target` seconds of CPU work in total."""
-    import ctypes as C
     import threading
     from oracle import oracle as O
     O.build()
@@ -151,22 +159,515 @@ def cpu_baseline(blocks, pre, cpu_seconds_target=16.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--messages-per-gpu", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_digest(message, max_size, range_check, cpu_seconds_target=6.0):
+    """The reference's own bench workload on the CPU: ONE Sha256DynamicConfig::digest with every cell of
+    the region (prologue, max_size/64 blocks, epilogue, lookup column, chip columns -- oracle_digest_cells,
+    the restatement of lib.rs:71-349 under A1-A4), checks off, streams written to pre-mapped buffers.
+    First on one thread -- the reference's synthesize() is single-threaded -- then one synthesis per core."""
+    import ctypes as C
+    import threading
+    from oracle import oracle as O
+    O.build()
+    L = O.lib()
+    nblk = max_size // 64
+    G, LC = O.measure_shape(8, 2, True)
+    LK = O.lookup_cells_per_block(8, 2)
+    gcap = 64 + 5 * max_size + nblk * G + 76 * (nblk + 1) + 288
+    lcap = 8 + 2 * max_size + nblk * LK + 64
+    msg = np.frombuffer(bytes(message), dtype=np.uint8).copy()
 
+    def make_bufs():
+        b = (np.zeros((gcap, 4), dtype=np.uint64), np.zeros((lcap, 4), dtype=np.uint64),
+             np.zeros((2, nblk * LC // 2 + 1, 4), dtype=np.uint64), np.zeros((2, nblk * LC // 2 + 1, 4), dtype=np.uint64))
+        return b
+
+    def synth(bufs):
+        gate, lookup, dense, spread = bufs
+        h = L.oracle_create(8, 2, 0)                 # a fresh Context + SpreadConfig per synthesis (lib.rs:440)
+        L.oracle_set_internals(h, 1)
+        L.oracle_set_outputs(h, gate.ctypes.data, gcap, dense.ctypes.data, spread.ctypes.data, dense.shape[1], 0)
+        L.oracle_set_lookup_output(h, lookup.ctypes.data, lcap)
+        dig = np.zeros(32, dtype=np.uint8)
+        lay = O.DigestLayout()
+        rc = L.oracle_digest_cells(h, msg.ctypes.data, len(msg), 0, max_size, 1 if range_check else 0,
+                                   dig.ctypes.data, C.byref(lay))
+        L.oracle_destroy(h)
+        assert rc < 10
+        return dig.tobytes()
+
+    import hashlib
+    bufs = make_bufs()
+    assert synth(bufs) == hashlib.sha256(bytes(message)).digest()
+    t0 = time.perf_counter()
+    reps1 = 0
+    while time.perf_counter() - t0 < cpu_seconds_target / 3 or reps1 < 3:
+        synth(bufs)
+        reps1 += 1
+    dt1 = (time.perf_counter() - t0) / reps1
+    cores = host_cores()
+    rounds = max(2, int(round(cpu_seconds_target * 2 / 3 / dt1 / 1.0)) // max(1, cores) + 1)
+    res = [0.0] * cores
+    barrier = threading.Barrier(cores)
+
+    def work(i):
+        b = make_bufs()
+        synth(b)
+        barrier.wait()
+        t = time.perf_counter()
+        for _ in range(rounds):
+            synth(b)
+        res[i] = time.perf_counter() - t
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = max(res)
+    return {
+        "value": nblk / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
+        "ms_per_synthesis": dt1 * 1e3,
+        "sample": "%d syntheses of the benches/digest.rs region (1 x %d-byte message, max %d B = %d blocks, range "
+                  "checks %s) on ONE thread -- the reference's synthesize() is single-threaded; oracle/hsw_oracle.c "
+                  "oracle_digest_cells, checks off, all streams written" % (reps1, len(message), max_size, nblk,
+                                                                             "on" if range_check else "off"),
+        "all_cores": {"value": cores * rounds * nblk / wall, "unit": "blocks/s", "cores": cores,
+                      "ms_per_synthesis_amortised": wall / (cores * rounds) * 1e3,
+                      "sample": "%d threads x %d independent syntheses" % (cores, rounds)},
+    }
+
+
+# ------------------------------------------------------------------ N > 1: start the ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (one per GPU)
+    and relay rank 0's JSON line.  Runs BEFORE this process touches HIP (torch.cuda.device_count() does
+    not initialise the GPU on this image), and never re-execs anything: the ranks are children."""
+    n = args.gpus
+    same_device = os.environ.get("HSW_BENCH_SAME_DEVICE") == "1"      # rehearsal on a 1-GPU box (with HSW_BENCH_BACKEND=gloo)
+    import torch
+    visible = torch.cuda.device_count()
+    if not same_device and visible < n:
+        sys.stderr.write("bench.py: --gpus %d asked for, but only %d GPU(s) visible\n" % (n, visible))
+        return 2
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(_free_port()))
+    env0["WORLD_SIZE"] = str(n)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0)
+        env["RANK"] = env["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                  # exactly the child we started
+            rcs.append(-9)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------ extras (rank 0, outside the timed region)
+def extra_representations(hsw, eng, blocks, pre, cursor0, out, n, alg_bytes, step):
+    extra = {}
+    # same batch with cells in Montgomery form (x * 2^256 mod p: halo2curves' in-memory Fr)
+    try:
+        for _ in range(2):
+            eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
+        mm = []
+        for _ in range(5):
+            eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
+            mm.append(eng.last_kernel_ms())
+        m_ms = float(np.median(mm))
+        extra["montgomery_repr"] = {"kernel": eng.last_launch()["kernel"], "kernel_ms": m_ms, "blocks_per_s": n / m_ms * 1e3,
+                                    "GBps": alg_bytes * n / m_ms / 1e6, "frac_of_peak": alg_bytes * n / m_ms / 1e6 / HBM_PEAK_GBS}
+        try:     # the Montgomery stream checked on the device (cells reduced on load)
+            reps_m = [eng.verify_blocks(blocks, pre, out, cursor0=cursor0, flags=hsw.HSW_REPR_MONTGOMERY) for _ in range(3)]
+            extra["montgomery_repr"]["verify_on_device"] = {
+                "violations": reps_m[-1]["violations"], "kernel_ms": float(np.median([r["kernel_ms"] for r in reps_m]))}
+        except Exception as ex:
+            extra["montgomery_repr"]["verify_on_device"] = {"error": repr(ex)}
+        step()      # leave canonical cells in the buffers
+    except Exception as ex:
+        extra["montgomery_repr"] = {"error": repr(ex)}
+    # 8-byte transport cells (HSW_REPR_COMPACT64): a quarter of the bytes, so no longer HBM-bound
+    try:
+        oc = eng.alloc_outputs(n, cursor0, hsw.HSW_REPR_COMPACT64)
+        cm = []
+        for i in range(7):
+            eng.witness_blocks(blocks, pre, cursor0=cursor0, out=oc, flags=hsw.HSW_REPR_COMPACT64)
+            if i >= 2:
+                cm.append(eng.last_kernel_ms())
+        c_ms = float(np.median(cm))
+        cbytes = (alg_bytes - 128) // 4 + 128
+        extra["compact64_repr"] = {"kernel": eng.last_launch()["kernel"], "kernel_ms": c_ms, "blocks_per_s": n / c_ms * 1e3,
+                                   "GBps": cbytes * n / c_ms / 1e6, "bound": "instruction issue / LDS, not HBM"}
+        del oc
+    except Exception as ex:
+        extra["compact64_repr"] = {"error": repr(ex)}
+    # the product's own MockProver-style check of the batch just written, in HBM (hsw_verify_blocks)
+    try:
+        step()
+        reps_v = [eng.verify_blocks(blocks, pre, out, cursor0=cursor0) for _ in range(3)]
+        vms = float(np.median([r["kernel_ms"] for r in reps_v]))
+        extra["verify_on_device"] = {"violations": reps_v[-1]["violations"], "checks": reps_v[-1]["checks"],
+                                     "kernel_ms": vms, "blocks_per_s": n / vms * 1e3,
+                                     "read_GBps": alg_bytes * n / vms / 1e6,
+                                     "note": "every gate row, copy constraint, constant, range bound, chip cell / spread-table row and next state of all blocks"}
+    except Exception as ex:
+        extra["verify_on_device"] = {"error": repr(ex)}
+    return extra
+
+
+def extra_config1(hsw, eng, dev, local_rank, alg_bytes):
+    """configs[1]: one 1 KiB-class message = 16 chained blocks (1,015 bytes)."""
+    import hashlib
+    import torch
+    res = {}
+    m = bytes(((i * 131 + 7) % 256) for i in range(1015))
+    padded = bytearray(m) + b"\x80" + b"\x00" * ((64 - (len(m) + 9) % 64) % 64) + (8 * len(m)).to_bytes(8, "big")
+    assert len(padded) == 1024
+    b16 = torch.from_numpy(np.frombuffer(bytes(padded), dtype=np.uint8).reshape(16, 64).copy()).to(dev)
+    o16 = eng.alloc_outputs(16, 0)
+    for _ in range(3):
+        p16 = eng.sha256_chain(b16, 1, 16)
+        eng.witness_blocks(b16, p16, out=o16)
+    torch.cuda.synchronize()
+    reps = 50
+    km = []
+    for _ in range(12):                             # the expansion launch alone (HIP events on the engine's stream)
+        eng.witness_blocks(b16, p16, out=o16)
+        km.append(eng.last_kernel_ms())
+    k_ms = float(np.median(km[2:]))
+    li = eng.last_launch()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        p16 = eng.sha256_chain(b16, 1, 16)
+        eng.witness_blocks(b16, p16, out=o16)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / reps
+    last = o16["next_states"][15].cpu().numpy().view(np.uint32)
+    assert b"".join(int(x).to_bytes(4, "big") for x in last) == hashlib.sha256(m).digest()
+    res["expand_kernel"] = {"kernel": li["kernel"], "parts": li["parts"], "split": li["split"], "ms": k_ms,
+                            "GBps": 16 * alg_bytes / k_ms / 1e6, "frac_of_peak": 16 * alg_bytes / k_ms / 1e6 / HBM_PEAK_GBS}
+    res["device_resident_chain_plus_expand"] = {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt,
+                                                "GBps": 16 * alg_bytes / dt / 1e9,
+                                                "frac_of_peak": 16 * alg_bytes / dt / 1e9 / HBM_PEAK_GBS}
+    try:   # the same two launches captured into one HIP graph and replayed
+        gs = torch.cuda.Stream()
+        eng_g = hsw.WitnessEngine(local_rank, 8, 2, stream=gs)
+        with torch.cuda.stream(gs):
+            pg = eng_g.sha256_chain(b16, 1, 16)
+            eng_g.witness_blocks(b16, pg, out=o16)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=gs):
+            pg = eng_g.sha256_chain(b16, 1, 16)
+            eng_g.witness_blocks(b16, pg, out=o16)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - t1) / reps
+        res["hip_graph_replay"] = {"ms_per_message": dtr * 1e3, "blocks_per_s": 16 / dtr}
+        del graph
+        eng_g.close()
+    except Exception as ex:
+        res["hip_graph_replay"] = {"error": repr(ex)}
+    # the same message through the gadget front-end (Sha256DynamicConfig::digest, lib.rs:71-349):
+    # host padding + chain, one expansion launch, the states back, sync
+    cfg = hsw.Sha256DynamicConfig(eng, [1024] * 64, True)
+    for _ in range(4):
+        cfg.digest(m)
+    tg = []
+    for _ in range(50):
+        t1 = time.perf_counter()
+        r = cfg.digest(m)
+        tg.append(time.perf_counter() - t1)
+    dtg = float(np.median(tg))
+    assert r.output_bytes == hashlib.sha256(m).digest()
+    cfg.close()
+    res["gadget_digest_end_to_end"] = {
+        "ms_per_message": dtg * 1e3, "blocks_per_s": 16 / dtg, "ms_mean": float(np.mean(tg)) * 1e3,
+        "ms_max": float(np.max(tg)) * 1e3, "slowest_iteration": int(np.argmax(tg))}
+    return res
+
+
+def extra_config0(hsw, local_rank, with_cpu):
+    """BASELINE configs[0] = the reference's own bench circuit (benches/digest.rs:93,102-109,129): one 56-byte
+    message, max 1024 B => 16 blocks synthesised, input range checks, k = 17 -- as the literal advice-column
+    image of the whole region (SURVEY 8 f2 + f4, assumptions A1-A4): 9 FlexGate columns x 131,063 rows + the
+    lookup column + the chip columns.  north_star's target is stated on this workload, so it carries its own
+    roofline fraction and cpu_baseline."""
+    import ctypes as C
+    import hashlib
+    res = {}
+    eng_i = hsw.WitnessEngine(local_rank, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    cfgw = hsw.Sha256DynamicConfig(eng_i, [1024], True, whole_digest=True)
+    ncol = cfgw.set_columns((1 << 17) - 9)
+    m56 = bytes([1] * 56)
+    for _ in range(4):
+        cfgw.reset()
+        rw = cfgw.digest(m56)
+    tw = []
+    for _ in range(50):
+        cfgw.reset()
+        t1 = time.perf_counter()
+        rw = cfgw.digest(m56)
+        tw.append(time.perf_counter() - t1)
+    dtw = float(np.median(tw))
+    assert rw.output_bytes == hashlib.sha256(m56).digest()
+    vw = cfgw.view()
+    chip_cells = 2 * int(vw.num_limb_sum)
+    region_bytes = (int(vw.gate_cells) + int(vw.lookup_cells) + chip_cells) * 32
+    # ... and on to the host, where a CPU prover (create_proof) would read the advice columns
+    hostimg = cfgw.download_region(pinned=True)
+    dst = hsw._native.RegionHost(hostimg["gate"].ctypes.data, hostimg["lookup"].ctypes.data, None, None)
+    tdl = []
+    for _ in range(7):
+        cfgw.reset()
+        t1 = time.perf_counter()
+        rw = cfgw.digest(m56)
+        assert eng_i.lib.hsw_gadget_download_region(cfgw.h, C.byref(dst)) == 0
+        tdl.append(time.perf_counter() - t1)
+    vrep = cfgw.verify()
+    res["whole_region"] = {
+        "ms_per_synthesis": dtw * 1e3, "ms_min": float(np.min(tw)) * 1e3, "blocks_per_s": 16 / dtw, "advice_columns": ncol,
+        "gate_cells": int(vw.gate_cells), "lookup_cells": int(vw.lookup_cells), "chip_cells": chip_cells,
+        "kernel": eng_i.last_launch()["kernel"], "parts": eng_i.last_launch()["parts"], "split": eng_i.last_launch()["split"],
+        "note": "Sha256DynamicConfig::digest of benches/digest.rs through hsw_gadget_digest: prologue + 16 blocks + "
+                "epilogue written as FlexGate columns + lookup column + chip columns in HBM, states back on the host"}
+    res["roofline"] = {"bound": "hbm", "achieved": region_bytes / dtw / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": region_bytes / dtw / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": region_bytes,
+                       "note": "a 41 MB launch is latency-bound (launch + 64-round chain + the longest unit program), "
+                               "not bandwidth-bound; the fraction is reported because north_star states its target on this workload"}
+    res["whole_region_verify"] = {
+        "violations": vrep["violations"], "checks": vrep["checks"], "kernel_ms": vrep["kernel_ms"],
+        "note": "hsw_gadget_verify: blocks + frames + links of the whole region, column image, on the device"}
+    res["whole_region_to_host"] = {
+        "ms_per_synthesis": float(np.median(tdl)) * 1e3, "bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
+        "note": "synthesis + D2H of the used rows of the 9 gate columns and the lookup column into pinned memory (PCIe-bound); the chip columns would add 2 x 2 x 32,960 cells"}
+    cfgw.close()
+    eng_i.close()
+    if with_cpu:
+        try:
+            cb = cpu_baseline_digest(m56, 1024, True)
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu_1thread"] = cb["ms_per_synthesis"] / (dtw * 1e3)
+            res["speedup_vs_cpu_all_cores"] = cb["all_cores"]["ms_per_synthesis_amortised"] / (dtw * 1e3)
+        except Exception as ex:
+            res["cpu_baseline"] = {"error": repr(ex)}
+    return res
+
+
+def extra_config2_regions(hsw, local_rank, msgs, n):
+    """configs[2] as whole regions: 4,096 single-block digests, each with its prologue / epilogue cells
+    (551 per digest) and the lookup column -- ONE framed expansion launch + one frame launch."""
+    import ctypes as C
+    import hashlib
+    eng_i = hsw.WitnessEngine(local_rank, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    nd = n
+    bufs = [(C.c_uint8 * len(mm)).from_buffer_copy(mm.tobytes()) for mm in msgs[:nd]]
+    ptrs = (C.c_void_p * nd)(*[C.addressof(b) for b in bufs])
+    lens_ = (C.c_size_t * nd)(*[len(mm) for mm in msgs[:nd]])
+    pres_ = (C.c_size_t * nd)(*([0] * nd))
+    resv = (hsw._native.HashResult * nd)()
+    cfgb = hsw.Sha256DynamicConfig(eng_i, [64] * nd, False, whole_digest=True)
+    tsb = []
+    for i in range(6):
+        cfgb.reset()
+        t1 = time.perf_counter()
+        rcb = eng_i.lib.hsw_gadget_digest_batch(cfgb.h, nd, ptrs, lens_, pres_, resv)
+        tsb.append(time.perf_counter() - t1)
+        assert rcb == 0
+    dtb = float(np.median(tsb[2:]))
+    assert bytes(resv[5].output_bytes) == hashlib.sha256(msgs[5].tobytes()).digest()
+    vb = cfgb.view()
+    out = {"digests": nd, "ms": dtb * 1e3, "digests_per_s": nd / dtb, "gate_cells": int(vb.gate_cells),
+           "lookup_cells": int(vb.lookup_cells),
+           "note": "host padding + H2D + chain + framed expansion + frames + D2H of the states, through hsw_gadget_digest_batch"}
+    cfgb.close()
+    eng_i.close()
+    return out
+
+
+def extra_config4_substitute(hsw, eng, local_rank, blocks_h, pre_h, alg_bytes):
+    """BASELINE configs[4] needs the Rust prover (create_proof at k=20): not runnable here.  SURVEY 8d
+    substitute: the witness columns of a k=20-sized circuit (~120 blocks at 9 advice columns) delivered to
+    HOST memory, where a CPU MSM/FFT prover would read them.  PCIe-bound by construction."""
+    import ctypes as C
+    import hashlib
+    res = {}
+    nb = 120
+    t1 = time.perf_counter()
+    hostout = eng.witness_blocks_host(blocks_h[:nb], pre_h[:nb], cursor0=0, pinned=True)
+    t_first = time.perf_counter() - t1
+    keep = hostout          # reuse the pinned buffers: time steady-state calls through the C ABI
+    reps = 5
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        rc = eng.lib.hsw_witness_blocks_host(
+            eng.h, blocks_h[:nb].ctypes.data, pre_h[:nb].ctypes.data, nb, 0, keep["gate"].ctypes.data,
+            keep["dense"].ctypes.data, keep["spread"].ctypes.data, keep["dense"].shape[1], None, 0)
+        assert rc == 0
+    dt = (time.perf_counter() - t1) / reps
+    res["block_streams_to_host"] = {
+        "blocks": nb, "ms": dt * 1e3, "blocks_per_s": nb / dt, "host_GBps": nb * alg_bytes / dt / 1e9,
+        "first_call_ms": t_first * 1e3,
+        "note": "create_proof itself is not runnable (no Rust toolchain); pinned host buffers, PCIe Gen5 x16 spec 63 GB/s"}
+    del hostout, keep
+    # same delivery in the 8-byte transport form (HSW_REPR_COMPACT64): 4x fewer bytes over PCIe
+    hc = eng.witness_blocks_host(blocks_h[:nb], pre_h[:nb], cursor0=0, pinned=True, flags=hsw.HSW_REPR_COMPACT64)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        rc = eng.lib.hsw_witness_blocks_host(
+            eng.h, blocks_h[:nb].ctypes.data, pre_h[:nb].ctypes.data, nb, 0, hc["gate"].ctypes.data,
+            hc["dense"].ctypes.data, hc["spread"].ctypes.data, hc["dense"].shape[1], None, hsw.HSW_REPR_COMPACT64)
+        assert rc == 0
+    dtc = (time.perf_counter() - t1) / reps
+    res["block_streams_to_host"]["compact64_transport"] = {
+        "ms": dtc * 1e3, "blocks_per_s": nb / dtc, "host_GBps": nb * (alg_bytes // 4) / dtc / 1e9}
+    del hc
+    # the same circuit size as ONE whole region: a k = 20 context (max_rows = 2^20 - 9, lib.rs:351-360) of
+    # eight digests summing to 120 blocks, input range checks on -- the column image of every advice cell
+    try:
+        eng_i = hsw.WitnessEngine(local_rank, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+        sizes = [1024] * 7 + [512]
+        msgs = [bytes(((i * 7 + 3 * k) % 256) for i in range(s - 9 - 5 * k)) for k, s in enumerate(sizes)]
+        cfg = hsw.Sha256DynamicConfig(eng_i, sizes, True, whole_digest=True)
+        ncol = cfg.set_columns((1 << 20) - 9)
+        for _ in range(2):
+            cfg.reset()
+            rs = cfg.digest_batch(msgs)
+        ts = []
+        for _ in range(10):
+            cfg.reset()
+            t1 = time.perf_counter()
+            rs = cfg.digest_batch(msgs)
+            ts.append(time.perf_counter() - t1)
+        assert all(r.output_bytes == hashlib.sha256(m).digest() for r, m in zip(rs, msgs))
+        v = cfg.view()
+        img = cfg.download_region(pinned=True)
+        dst = hsw._native.RegionHost(img["gate"].ctypes.data, img["lookup"].ctypes.data,
+                                     img["dense"].ctypes.data, img["spread"].ctypes.data)
+        td = []
+        for _ in range(5):
+            cfg.reset()
+            t1 = time.perf_counter()
+            cfg.digest_batch(msgs)
+            assert eng_i.lib.hsw_gadget_download_region(cfg.h, C.byref(dst)) == 0
+            td.append(time.perf_counter() - t1)
+        vrep = cfg.verify()
+        nbytes = (int(v.gate_cells) + int(v.lookup_cells) + 2 * int(v.num_limb_sum)) * 32
+        res["whole_region_k20"] = {
+            "digests": len(sizes), "blocks": sum(sizes) // 64, "advice_columns": ncol, "max_rows": (1 << 20) - 9,
+            "gate_cells": int(v.gate_cells), "lookup_cells": int(v.lookup_cells),
+            "synthesis_ms": float(np.median(ts)) * 1e3, "synthesis_GBps": nbytes / float(np.median(ts)) / 1e9,
+            "synthesis_plus_download_ms": float(np.median(td)) * 1e3,
+            "host_GBps": nbytes / float(np.median(td)) / 1e9,
+            "verify": {"violations": vrep["violations"], "checks": vrep["checks"], "kernel_ms": vrep["kernel_ms"]},
+            "note": "the advice-column image of a k = 20 region (8 digests, 120 blocks, input range checks) synthesised in HBM, "
+                    "then gate + lookup + chip columns delivered to pinned host memory for a CPU prover"}
+        cfg.close()
+        eng_i.close()
+    except Exception as ex:
+        res["whole_region_k20"] = {"error": repr(ex)}
+    return res
+
+
+def extra_multi_gpu(dist, sh, eng, blocks, pre, out, n, world, rank, value):
+    """north_star's all-gather of witness columns over xGMI (RCCL), on a bounded shard: 256 blocks (543 MB of
+    gate cells) per rank.  Reported separately, never in `value`.  Symmetric on all ranks; a failure is
+    recorded, not fatal."""
+    import torch
+    res = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+           "kernel_only_blocks_per_s": value}
+    try:
+        nb = min(256, n)
+        oshard = eng.alloc_outputs(nb, 0)
+        eng.witness_blocks(blocks[:nb], pre[:nb], cursor0=0, out=oshard)
+        shard = oshard["gate"]
+        counts = [nb] * world
+        gathered = sh.allgather_gate(dist, shard, counts, eng.G)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            eng.witness_blocks(blocks[:nb], pre[:nb], cursor0=0, out=oshard)    # the shard's kernel ...
+            gathered = sh.allgather_gate(dist, shard, counts, eng.G)            # ... + its all-gather
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = (time.perf_counter() - t1) / reps
+        shard_bytes = shard.numel() * 8
+        same = bool((gathered[rank * nb * eng.G:(rank + 1) * nb * eng.G] == shard).all())
+        res["allgather"] = {"shard_blocks": nb, "shard_bytes": shard_bytes, "ms": dt * 1e3, "own_shard_intact": same,
+                            "recv_GBps_per_gpu": shard_bytes * (world - 1) / dt / 1e9}
+        res["kernel_plus_allgather_blocks_per_s"] = nb * world / dt
+        del gathered
+    except Exception as ex:
+        res["allgather"] = {"error": repr(ex)}
+    # The cheaper equivalent (SURVEY 8e): exchange the 96-byte seeds and let every GPU
+    # re-expand all ranks' blocks into its own HBM.  Bounded: 1,024 blocks per rank.
+    try:
+        nb = min(1024, n)
+        counts = [nb] * world
+        allout = eng.alloc_outputs(nb * world, 0)
+
+        def replicate():
+            sb, sp = sh.allgather_seeds(dist, blocks[:nb], pre[:nb], counts)
+            eng.witness_blocks(sb, sp, cursor0=0, out=allout)
+        replicate()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            replicate()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = (time.perf_counter() - t1) / reps
+        res["replicate_by_seed_exchange"] = {
+            "blocks_per_rank": nb, "ms": dt * 1e3, "blocks_per_s_replicated_on_every_gpu": nb * world / dt,
+            "xgmi_bytes_per_block": 96, "note": "every GPU ends with all ranks' witness columns in its own HBM"}
+        del allout
+    except Exception as ex:
+        res["replicate_by_seed_exchange"] = {"error": repr(ex)}
+    return res
+
+
+# ------------------------------------------------------------------ one rank
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and "WORLD_SIZE" in os.environ and args.gpus != 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     distributed = world > 1 or os.environ.get("HSW_BENCH_FORCE_DIST") == "1"   # force: 1-rank RCCL rehearsal
     # Rehearsal knobs (not used by the driver): HSW_BENCH_BACKEND=gloo and HSW_BENCH_SAME_DEVICE=1 run
     # the multi-rank control flow on a box with ONE GPU (all ranks on cuda:0, collectives on the CPU).
@@ -175,6 +676,7 @@ def main():
         local_rank = 0
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
@@ -194,9 +696,7 @@ def main():
     rng = np.random.default_rng(0xC3 + rank)
     msgs = rng.integers(0, 256, (n, 55), dtype=np.uint8)
     blocks_h = sha_pad_single_block(msgs)
-    iv = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
-                   0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
-    pre_h = np.tile(iv, (n, 1))
+    pre_h = np.tile(IV, (n, 1))
     blocks = torch.from_numpy(blocks_h).to(dev)
     pre = torch.from_numpy(pre_h.view(np.int32)).to(dev)
     sh = importlib.import_module("halo2-dynamic-sha256_amd.sharding")
@@ -231,6 +731,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms_avg = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # avg launch duration over the timed region
+    launched = eng.last_launch()                                          # the instantiation that was timed
     # cross-check with the engine's own event pair (hsw_last_kernel_ms) on one more launch
     step()
     kernel_ms_engine = eng.last_kernel_ms()
@@ -257,285 +758,46 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0:
-        # same batch with cells in Montgomery form (x * 2^256 mod p: halo2curves' in-memory Fr)
+        extra.update(extra_representations(hsw, eng, blocks, pre, cursor0, out, n, alg_bytes, step))
         try:
-            for _ in range(2):
-                eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
-            mm = []
-            for _ in range(5):
-                eng.witness_blocks(blocks, pre, cursor0=cursor0, out=out, flags=hsw.HSW_REPR_MONTGOMERY)
-                mm.append(eng.last_kernel_ms())
-            m_ms = float(np.median(mm))
-            extra["montgomery_repr"] = {"kernel_ms": m_ms, "blocks_per_s": n / m_ms * 1e3,
-                                        "GBps": alg_bytes * n / m_ms / 1e6, "frac_of_peak": alg_bytes * n / m_ms / 1e6 / HBM_PEAK_GBS}
-            try:     # the Montgomery stream checked on the device (cells reduced on load)
-                reps_m = [eng.verify_blocks(blocks, pre, out, cursor0=cursor0, flags=hsw.HSW_REPR_MONTGOMERY) for _ in range(3)]
-                extra["montgomery_repr"]["verify_on_device"] = {
-                    "violations": reps_m[-1]["violations"], "kernel_ms": float(np.median([r["kernel_ms"] for r in reps_m]))}
-            except Exception as ex:
-                extra["montgomery_repr"]["verify_on_device"] = {"error": repr(ex)}
-            step()      # leave canonical cells in the buffers
+            extra["config1_1KiB_message_16_blocks"] = extra_config1(hsw, eng, dev, local_rank, alg_bytes)
         except Exception as ex:
-            extra["montgomery_repr"] = {"error": repr(ex)}
-        # 8-byte transport cells (HSW_REPR_COMPACT64): a quarter of the bytes, so no longer HBM-bound
+            extra["config1_1KiB_message_16_blocks"] = {"error": repr(ex)}
         try:
-            oc = eng.alloc_outputs(n, cursor0, hsw.HSW_REPR_COMPACT64)
-            cm = []
-            for i in range(7):
-                eng.witness_blocks(blocks, pre, cursor0=cursor0, out=oc, flags=hsw.HSW_REPR_COMPACT64)
-                if i >= 2:
-                    cm.append(eng.last_kernel_ms())
-            c_ms = float(np.median(cm))
-            cbytes = (alg_bytes - 128) // 4 + 128
-            extra["compact64_repr"] = {"kernel_ms": c_ms, "blocks_per_s": n / c_ms * 1e3,
-                                       "GBps": cbytes * n / c_ms / 1e6, "bound": "instruction issue / LDS, not HBM"}
-            del oc
+            extra["config0_benches_digest_rs"] = extra_config0(hsw, local_rank, not args.no_cpu_baseline)
         except Exception as ex:
-            extra["compact64_repr"] = {"error": repr(ex)}
-    if not args.no_extra and rank == 0:
-        # the product's own MockProver-style check of the batch just written, in HBM (hsw_verify_blocks)
+            extra["config0_benches_digest_rs"] = {"error": repr(ex)}
         try:
-            reps_v = [eng.verify_blocks(blocks, pre, out, cursor0=cursor0) for _ in range(3)]
-            vms = float(np.median([r["kernel_ms"] for r in reps_v]))
-            extra["verify_on_device"] = {"violations": reps_v[-1]["violations"], "checks": reps_v[-1]["checks"],
-                                         "kernel_ms": vms, "blocks_per_s": n / vms * 1e3,
-                                         "read_GBps": alg_bytes * n / vms / 1e6,
-                                         "note": "every gate row, copy constraint, constant, range bound, chip cell / spread-table row and next state of all blocks"}
+            extra["config2_as_whole_regions"] = extra_config2_regions(hsw, local_rank, msgs, n)
         except Exception as ex:
-            extra["verify_on_device"] = {"error": repr(ex)}
-    if not args.no_extra and rank == 0:
-        # configs[1]: one 1 KiB-class message = 16 chained blocks (1,015 bytes)
-        m = bytes(((i * 131 + 7) % 256) for i in range(1015))
-        padded = bytearray(m) + b"\x80" + b"\x00" * ((64 - (len(m) + 9) % 64) % 64) + (8 * len(m)).to_bytes(8, "big")
-        assert len(padded) == 1024
-        b16 = torch.from_numpy(np.frombuffer(bytes(padded), dtype=np.uint8).reshape(16, 64).copy()).to(dev)
-        o16 = eng.alloc_outputs(16, 0)
-        for _ in range(3):
-            p16 = eng.sha256_chain(b16, 1, 16)
-            eng.witness_blocks(b16, p16, out=o16)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        reps = 50
-        for _ in range(reps):
-            p16 = eng.sha256_chain(b16, 1, 16)
-            eng.witness_blocks(b16, p16, out=o16)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / reps
-        last = o16["next_states"][15].cpu().numpy().view(np.uint32)
-        assert b"".join(int(x).to_bytes(4, "big") for x in last) == hashlib.sha256(m).digest()
-        extra["config1_1KiB_message_16_blocks"] = {
-            "device_resident_chain_plus_expand": {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt},
-        }
-        try:   # the same two launches captured into one HIP graph and replayed
-            gs = torch.cuda.Stream()
-            eng_g = hsw.WitnessEngine(local_rank, 8, 2, stream=gs)
-            with torch.cuda.stream(gs):
-                pg = eng_g.sha256_chain(b16, 1, 16)
-                eng_g.witness_blocks(b16, pg, out=o16)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=gs):
-                pg = eng_g.sha256_chain(b16, 1, 16)
-                eng_g.witness_blocks(b16, pg, out=o16)
-            for _ in range(3):
-                graph.replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                graph.replay()
-            torch.cuda.synchronize()
-            dtr = (time.perf_counter() - t1) / reps
-            extra["config1_1KiB_message_16_blocks"]["hip_graph_replay"] = {"ms_per_message": dtr * 1e3,
-                                                                             "blocks_per_s": 16 / dtr}
-            del graph
-            eng_g.close()
-        except Exception as ex:
-            extra["config1_1KiB_message_16_blocks"]["hip_graph_replay"] = {"error": repr(ex)}
-        # the same message through the gadget front-end (Sha256DynamicConfig::digest, lib.rs:71-349):
-        # host padding + chain, H2D of the blocks, one expansion launch, D2H of the states, sync
-        cfg = hsw.Sha256DynamicConfig(eng, [1024] * 64, True)
-        for _ in range(4):
-            cfg.digest(m)
-        tg = []
-        for _ in range(50):
-            t1 = time.perf_counter()
-            r = cfg.digest(m)
-            tg.append(time.perf_counter() - t1)
-        dtg = float(np.median(tg))
-        assert r.output_bytes == hashlib.sha256(m).digest()
-        cfg.close()
-        extra["config1_1KiB_message_16_blocks"]["gadget_digest_end_to_end"] = {
-            "ms_per_message": dtg * 1e3, "blocks_per_s": 16 / dtg, "ms_mean": float(np.mean(tg)) * 1e3,
-            "ms_max": float(np.max(tg)) * 1e3, "slowest_iteration": int(np.argmax(tg))}
-        # BASELINE configs[0], the reference's own bench circuit (benches/digest.rs:103-129): one 56-byte
-        # message, max 1024 B, input range checks, k = 17 -- as the literal advice-column image of the whole
-        # region (SURVEY 8 f2 + f4, assumptions A1-A4): 9 FlexGate columns x 131,063 rows + the lookup column
+            extra["config2_as_whole_regions"] = {"error": repr(ex)}
         try:
-            eng_i = hsw.WitnessEngine(local_rank, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
-            cfgw = hsw.Sha256DynamicConfig(eng_i, [1024], True, whole_digest=True)
-            ncol = cfgw.set_columns((1 << 17) - 9)
-            m56 = bytes([1] * 56)
-            for _ in range(4):
-                cfgw.reset()
-                rw = cfgw.digest(m56)
-            t1 = time.perf_counter()
-            for _ in range(50):
-                cfgw.reset()
-                rw = cfgw.digest(m56)
-            dtw = (time.perf_counter() - t1) / 50
-            assert rw.output_bytes == hashlib.sha256(m56).digest()
-            # ... and on to the host, where a CPU prover (create_proof) would read the advice columns
-            hostimg = cfgw.download_region(pinned=True)
-            dst = hsw._native.RegionHost(hostimg["gate"].ctypes.data, hostimg["lookup"].ctypes.data, None, None)
-            import ctypes as C
-            tdl = []
-            for _ in range(7):
-                cfgw.reset()
-                t1 = time.perf_counter()
-                rw = cfgw.digest(m56)
-                assert eng_i.lib.hsw_gadget_download_region(cfgw.h, C.byref(dst)) == 0
-                tdl.append(time.perf_counter() - t1)
-            vrep = cfgw.verify()
-            vw = cfgw.view()
-            extra["config0_bench_circuit_whole_region_verify"] = {
-                "violations": vrep["violations"], "checks": vrep["checks"], "kernel_ms": vrep["kernel_ms"],
-                "note": "hsw_gadget_verify: blocks + frames + links of the whole region, column image, on the device"}
-            extra["config0_bench_circuit_whole_region_to_host"] = {
-                "ms_per_synthesis": float(np.median(tdl)) * 1e3, "bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
-                "note": "synthesis + D2H of the used rows of the 9 gate columns and the lookup column into pinned memory (PCIe-bound); the chip columns would add 2 x 2 x 32,960 cells"}
-            extra["config0_bench_circuit_whole_region"] = {
-                "ms_per_synthesis": dtw * 1e3, "blocks_per_s": 16 / dtw, "advice_columns": ncol,
-                "gate_cells": int(vw.gate_cells), "lookup_cells": int(vw.lookup_cells),
-                "note": "prologue + 16 blocks + epilogue of Sha256DynamicConfig::digest written as FlexGate columns in HBM"}
-            cfgw.close()
-            # configs[2] as whole regions: 4,096 single-block digests, each with its prologue / epilogue cells
-            # (551 per digest) and the lookup column -- ONE framed expansion launch + one frame launch
-            import ctypes as C
-            nd = n
-            bufs = [(C.c_uint8 * len(mm)).from_buffer_copy(mm.tobytes()) for mm in msgs[:nd]]
-            ptrs = (C.c_void_p * nd)(*[C.addressof(b) for b in bufs])
-            lens_ = (C.c_size_t * nd)(*[len(mm) for mm in msgs[:nd]])
-            pres_ = (C.c_size_t * nd)(*([0] * nd))
-            resv = (hsw._native.HashResult * nd)()
-            cfgb = hsw.Sha256DynamicConfig(eng_i, [64] * nd, False, whole_digest=True)
-            tsb = []
-            for i in range(6):
-                cfgb.reset()
-                t1 = time.perf_counter()
-                rcb = eng_i.lib.hsw_gadget_digest_batch(cfgb.h, nd, ptrs, lens_, pres_, resv)
-                tsb.append(time.perf_counter() - t1)
-                assert rcb == 0
-            dtb = float(np.median(tsb[2:]))
-            assert bytes(resv[5].output_bytes) == hashlib.sha256(msgs[5].tobytes()).digest()
-            vb = cfgb.view()
-            extra["config2_as_whole_regions"] = {
-                "digests": nd, "ms": dtb * 1e3, "digests_per_s": nd / dtb, "gate_cells": int(vb.gate_cells),
-                "lookup_cells": int(vb.lookup_cells),
-                "note": "host padding + H2D + chain + framed expansion + frames + D2H of the states, through hsw_gadget_digest_batch"}
-            cfgb.close()
-            eng_i.close()
+            extra["config4_substitute_k20"] = extra_config4_substitute(hsw, eng, local_rank, blocks_h, pre_h, alg_bytes)
         except Exception as ex:
-            extra["config0_bench_circuit_whole_region"] = {"error": repr(ex)}
-
-    if not args.no_extra and rank == 0:
-        # BASELINE configs[4] needs the Rust prover (create_proof at k=20): not runnable here.
-        # SURVEY 8d substitute: the witness columns of a k=20-sized circuit (~120 blocks at 9
-        # advice columns) delivered to HOST memory, where a CPU MSM/FFT prover would read them:
-        # pipelined kernel || D2H into pinned buffers.  PCIe-bound by construction.
-        try:
-            nb = 120
-            t1 = time.perf_counter()
-            hostout = eng.witness_blocks_host(blocks_h[:nb], pre_h[:nb], cursor0=0, pinned=True)
-            t_first = time.perf_counter() - t1
-            keep = hostout          # reuse the pinned buffers: time steady-state calls through the C ABI
-            reps = 5
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                rc = eng.lib.hsw_witness_blocks_host(
-                    eng.h, blocks_h[:nb].ctypes.data, pre_h[:nb].ctypes.data, nb, 0, keep["gate"].ctypes.data,
-                    keep["dense"].ctypes.data, keep["spread"].ctypes.data, keep["dense"].shape[1], None, 0)
-                assert rc == 0
-            dt = (time.perf_counter() - t1) / reps
-            extra["config4_substitute_k20_witness_to_host"] = {
-                "blocks": nb, "ms": dt * 1e3, "blocks_per_s": nb / dt, "host_GBps": nb * alg_bytes / dt / 1e9,
-                "first_call_ms": t_first * 1e3,
-                "note": "create_proof itself is not runnable (no Rust toolchain); pinned host buffers, PCIe Gen5 x16 spec 63 GB/s"}
-            del hostout, keep
-            # same delivery in the 8-byte transport form (HSW_REPR_COMPACT64): 4x fewer bytes over PCIe
-            hc = eng.witness_blocks_host(blocks_h[:nb], pre_h[:nb], cursor0=0, pinned=True, flags=hsw.HSW_REPR_COMPACT64)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                rc = eng.lib.hsw_witness_blocks_host(
-                    eng.h, blocks_h[:nb].ctypes.data, pre_h[:nb].ctypes.data, nb, 0, hc["gate"].ctypes.data,
-                    hc["dense"].ctypes.data, hc["spread"].ctypes.data, hc["dense"].shape[1], None, hsw.HSW_REPR_COMPACT64)
-                assert rc == 0
-            dtc = (time.perf_counter() - t1) / reps
-            extra["config4_substitute_k20_witness_to_host"]["compact64_transport"] = {
-                "ms": dtc * 1e3, "blocks_per_s": nb / dtc, "host_GBps": nb * (alg_bytes // 4) / dtc / 1e9}
-            del hc
-        except Exception as ex:
-            extra["config4_substitute_k20_witness_to_host"] = {"error": repr(ex)}
-
+            extra["config4_substitute_k20"] = {"error": repr(ex)}
     if distributed and not args.no_extra:
-        # north_star's all-gather of witness columns over xGMI (RCCL), on a bounded
-        # shard: 256 blocks (543 MB of gate cells) per rank.  Reported separately,
-        # never in `value`.  Symmetric on all ranks; a failure is recorded, not fatal.
-        try:
-            nb = min(256, n)
-            shard = out["gate"][: nb * eng.G]
-            counts = [nb] * world
-            gathered = sh.allgather_gate(dist, shard, counts, eng.G)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                gathered = sh.allgather_gate(dist, shard, counts, eng.G)
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = (time.perf_counter() - t1) / reps
-            shard_bytes = shard.numel() * 8
-            same = bool((gathered[rank * nb * eng.G:(rank + 1) * nb * eng.G] == shard).all())
-            extra["allgather"] = {"shard_bytes": shard_bytes, "ms": dt * 1e3, "own_shard_intact": same,
-                                  "recv_GBps_per_gpu": shard_bytes * (world - 1) / dt / 1e9,
-                                  "blocks_per_s_if_gathered": nb * world / dt}
-            del gathered
-        except Exception as ex:
-            extra["allgather"] = {"error": repr(ex)}
-        # The cheaper equivalent: exchange the 96-byte seeds and let every GPU
-        # re-expand all ranks' blocks into its own HBM.  Bounded: 1,024 blocks per rank.
-        try:
-            nb = min(1024, n)
-            counts = [nb] * world
-            allout = eng.alloc_outputs(nb * world, 0)
-            def replicate():
-                sb, sp = sh.allgather_seeds(dist, blocks[:nb], pre[:nb], counts)
-                eng.witness_blocks(sb, sp, cursor0=0, out=allout)
-            replicate()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                replicate()
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = (time.perf_counter() - t1) / reps
-            extra["replicate_by_seed_exchange"] = {
-                "blocks_per_rank": nb, "ms": dt * 1e3, "blocks_per_s_replicated_on_every_gpu": nb * world / dt,
-                "xgmi_bytes_per_block": 96, "note": "every GPU ends with all ranks' witness columns in its own HBM"}
-            del allout
-        except Exception as ex:
-            extra["replicate_by_seed_exchange"] = {"error": repr(ex)}
+        mg = extra_multi_gpu(dist, sh, eng, blocks, pre, out, n, world, rank, value)
+        if rank == 0:
+            extra["multi_gpu"] = mg
+    rccl_ranks = dist.get_world_size() if distributed else 1
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()      # the other ranks are done; rank 0 goes on to the CPU baseline alone
 
-    result = None
     if rank == 0:
         achieved = alg_bytes * n / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc["algorithmic_bytes_per_launch"] == alg_bytes * n:      # same workload as this run
-                traffic = pmc["hbm_traffic_bytes_per_launch"]
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(path):
+                    continue
+                pmc = json.load(open(path))
+                if pmc["algorithmic_bytes_per_launch"] == alg_bytes * n:      # same workload as this run
+                    traffic = pmc["hbm_traffic_bytes_per_launch"]
+                    traffic_src = "profiles/%s (rocprofv3 --pmc, separate passes; bytes per launch; kernel %s, measured at commit %s)" % (
+                        name, pmc.get("kernel", "?"), pmc.get("commit", "?"))
+                break
         except Exception:
             pass
         result = {
@@ -543,6 +805,7 @@ def main():
             "value": value,
             "unit": "blocks/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -566,23 +829,40 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes; bytes per launch)" if traffic else None,
+                "traffic_source": traffic_src,
                 "calibrated_fill_GBps": fill_gbs,
-                "kernel": "hsw::hsw_expand_kernel<2, 64, 32, 0, false> (64-cell tiles, 4 waves per block)",
+                "kernel": "%s, %d waves per block%s" % (launched["kernel"], launched["parts"],
+                                                         ", split phases" if launched["split"] else ""),
+                "launch": launched,
                 "kernel_ms": kernel_ms_avg,
                 "kernel_ms_engine_events": kernel_ms_engine,
                 "algorithmic_bytes_per_launch": alg_bytes * n,
             },
             "extra": extra,
         }
-        if not args.no_cpu_baseline and world == 1:
+        mont = extra.get("montgomery_repr", {})
+        if "kernel_ms" in mont:      # halo2curves' in-memory Fr: the form a Rust shim copies straight into the Region
+            result["roofline"]["montgomery"] = {"kernel": mont["kernel"], "kernel_ms": mont["kernel_ms"],
+                                                "achieved": mont["GBps"], "frac": mont["frac_of_peak"]}
+        if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(blocks_h, pre_h)
-        elif not args.no_cpu_baseline:
-            result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--messages-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))      # before anything touches HIP in this process
+    run_rank(args)
 
 
 if __name__ == "__main__":

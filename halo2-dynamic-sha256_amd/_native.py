@@ -63,6 +63,18 @@ class WitnessArgs(C.Structure):
                 ("frame_every", C.c_uint64), ("frame_cells", C.c_uint64), ("frame_lookups", C.c_uint64)]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("limbs", "tile_cells", "tile_rows", "repr", "internals", "parts", "split",
+                                          "reserved_")] + [("n_blocks", C.c_uint64), ("grid", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved_"}
+
+    def kernel_name(self):
+        return "hsw::hsw_expand_kernel<%d, %d, %d, %d, %s>" % (self.limbs, self.tile_cells, self.tile_rows, self.repr,
+                                                              "true" if self.internals else "false")
+
+
 class FrameShape(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_blocks", "prologue_cells", "epilogue_cells", "prologue_lookups", "epilogue_lookups",
@@ -134,7 +146,7 @@ SYMBOLS = (
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
-    "hsw_verify_frames", "hsw_gadget_verify",
+    "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch",
 )
 
 

@@ -282,6 +282,13 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
     return set_err(e, HSW_ERR_INVALID_ARG, "unknown option");
 } HSW_NO_UNWIND
 
+int hsw_last_launch(const hsw_engine *e, hsw_launch_info *out) try {
+    if (!e || !out) return HSW_ERR_INVALID_ARG;
+    if (e->last_launch.grid == 0) return HSW_ERR_INVALID_ARG;      // nothing launched yet
+    *out = e->last_launch;
+    return HSW_OK;
+} HSW_NO_UNWIND
+
 int hsw_set_timing(hsw_engine *e, int enabled) try {
     if (!e) return HSW_ERR_INVALID_ARG;
     e->timing = enabled != 0;
@@ -428,6 +435,19 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
         }
         he = hsw::launch_expand(p, e->limbs, tile, e->stream);
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_expand_kernel", he);
+        {
+            hsw_launch_info &li = e->last_launch;
+            const bool wide_internals = e->mode == HSW_MODE_HALO2_INTERNALS && e->limbs > 2;   // [64][32] tiles only
+            li.limbs = (uint32_t)e->limbs;
+            li.tile_cells = wide_internals ? 32u : tile == 6416 ? 64u : (uint32_t)tile;
+            li.tile_rows = wide_internals ? 64u : tile == 6416 ? 16u : 2048u / (uint32_t)tile;
+            li.repr = (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
+            li.internals = e->mode == HSW_MODE_HALO2_INTERNALS ? 1u : 0u;
+            li.parts = p.parts;
+            li.split = (p.flags & hsw::HSW_K_SPLIT) ? 1u : 0u;
+            li.n_blocks = n;
+            li.grid = (uint64_t)n * p.parts;
+        }
     }
     if (e->timing) {
         he = hipEventRecord(e->ev1, e->stream);
@@ -564,45 +584,46 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         e->slot_rows = ch_rows;
     }
     const size_t rows_total = (size_t)hsw_chip_rows(&e->shape, cursor0, n_blocks);
-    void *reg_gate = nullptr, *reg_cd = nullptr, *reg_cs = nullptr;      // what hipHostRegister was given
+    // HSW_HOST_REGISTER: pin the caller's output buffers in place so that the copies write them directly.
+    // hipHostRegister works on whole pages, and the runtime takes any copy that STARTS in a registered page
+    // for a copy to pinned memory -- all of it, also the part past the registered range (a GPU memory fault,
+    // found by the fuzzer with two small chip arrays that shared a heap page).  So only the page INTERIOR of
+    // a buffer is registered -- [lo rounded up, hi rounded down): pages the buffer owns entirely, whatever
+    // allocator it came from -- and every D2H copy is split at the registration boundary (d2h below): no byte
+    // outside the caller's buffer is ever pinned, and no copy starts on one side of the boundary and ends
+    // on the other.  The <= 2 edge fragments (< 4 KiB each) take the pageable path.
+    struct Reg {
+        uintptr_t lo = 0, hi = 0;      // registered range, empty if lo == hi
+        void open(const void *ptr, size_t bytes) {
+            const uintptr_t PAGE = 4096;
+            const uintptr_t a = ((uintptr_t)ptr + PAGE - 1) & ~(PAGE - 1), b = ((uintptr_t)ptr + bytes) & ~(PAGE - 1);
+            if (bytes < 16 * PAGE || b <= a) return;          // not worth a registration
+            if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) { lo = a; hi = b; }
+            else (void)hipGetLastError();                     // e.g. already pinned by the caller: copy as it is
+        }
+        void close() { if (hi > lo) (void)hipHostUnregister((void *)lo); lo = hi = 0; }
+    } reg_gate, reg_cd, reg_cs;
     if (pin) {
-        // Pin the caller's output buffers in place so that the copies write them directly.  hipHostRegister
-        // works on whole pages, and the runtime takes any copy that STARTS in a registered page for a copy to
-        // pinned memory -- all of it, also the part past the registered range (a GPU memory fault, found by
-        // the fuzzer with two small chip arrays that shared a heap page).  So a buffer is registered only when
-        // no other host buffer of this call touches its pages, and only from 1 MiB up (malloc serves those by
-        // mmap, so the edge pages hold nothing else); all of them or none.
-        const uintptr_t PAGE = 4096;
-        struct Range { uintptr_t lo, hi; bool candidate; void **slot; };
-        auto pages = [&](const void *ptr, size_t bytes, bool cand, void **slot) -> Range {
-            return Range{(uintptr_t)ptr & ~(PAGE - 1), ((uintptr_t)ptr + bytes + PAGE - 1) & ~(PAGE - 1), cand, slot};
-        };
-        const size_t MIN_BYTES = (size_t)1 << 20;
         const size_t gate_bytes = want_gate ? n_blocks * G * cb : 0;
         const size_t span = want_chip ? ((ncols - 1) * chip_col_stride + rows_total) * cb : 0;
-        Range r[6];
-        int nr = 0;
-        if (gate_bytes) r[nr++] = pages(gate, gate_bytes, gate_bytes >= MIN_BYTES, &reg_gate);
-        if (span) { r[nr++] = pages(chip_dense, span, span >= MIN_BYTES, &reg_cd); r[nr++] = pages(chip_spread, span, span >= MIN_BYTES, &reg_cs); }
-        r[nr++] = pages(blocks, n_blocks * 64, false, nullptr);
-        r[nr++] = pages(pre_states, n_blocks * 32, false, nullptr);
-        if (next_states) r[nr++] = pages(next_states, n_blocks * 32, false, nullptr);
-        bool safe = true;
-        for (int i = 0; i < nr && safe; i++)
-            for (int j = 0; j < nr && safe; j++)
-                if (i != j && r[i].candidate && r[i].lo < r[j].hi && r[j].lo < r[i].hi) safe = false;
-        if (safe) {
-            for (int i = 0; i < nr && safe; i++)
-                if (r[i].candidate) {
-                    if (hipHostRegister((void *)r[i].lo, r[i].hi - r[i].lo, hipHostRegisterDefault) == hipSuccess) *r[i].slot = (void *)r[i].lo;
-                    else safe = false;
-                }
-            if (!safe)      // all or none
-                for (int i = 0; i < nr; i++)
-                    if (r[i].candidate && *r[i].slot) { (void)hipHostUnregister(*r[i].slot); *r[i].slot = nullptr; }
-        }
-        (void)hipGetLastError();
+        if (gate_bytes) reg_gate.open(gate, gate_bytes);
+        if (span) { reg_cd.open(chip_dense, span); reg_cs.open(chip_spread, span); }
     }
+    // D2H copy of [dst, dst + bytes), cut where it crosses the edge of the registered range
+    auto d2h = [&](const Reg &rg, void *dst, const void *src, size_t bytes, hipStream_t st) -> hipError_t {
+        uintptr_t d = (uintptr_t)dst;
+        const uintptr_t end = d + bytes;
+        const uint8_t *sp = static_cast<const uint8_t *>(src);
+        const uintptr_t cuts[2] = {rg.lo, rg.hi};
+        for (int k = 0; k < 2 && rg.hi > rg.lo; k++)
+            if (cuts[k] > d && cuts[k] < end) {
+                const size_t n = cuts[k] - d;
+                hipError_t r = hipMemcpyAsync((void *)d, sp, n, hipMemcpyDeviceToHost, st);
+                if (r != hipSuccess) return r;
+                d += n; sp += n;
+            }
+        return end > d ? hipMemcpyAsync((void *)d, sp, end - d, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
     uint8_t *d_blocks = nullptr; uint32_t *d_pre = nullptr, *d_next = nullptr;
     do {
         if ((he = hipMalloc((void **)&d_blocks, n_blocks * 64)) != hipSuccess) { fail("hipMalloc blocks"); break; }
@@ -623,8 +644,8 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
             if (rc != HSW_OK) break;
             if ((he = hipEventRecord(s.kernel_done, e->stream)) != hipSuccess) { fail("record kernel_done"); break; }
             if ((he = hipStreamWaitEvent(e->copy_stream, s.kernel_done, 0)) != hipSuccess) { fail("wait kernel_done"); break; }
-            if (want_gate && (he = hipMemcpyAsync(static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
-                                                  nb * G * cb, hipMemcpyDeviceToHost, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
+            if (want_gate && (he = d2h(reg_gate, static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
+                                       nb * G * cb, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
             if (want_chip) {
                 // only the last chunk can end inside a row: the cells of that row past the call's last limb
                 // belong to the next call and must keep what the caller's buffer holds
@@ -633,11 +654,11 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
                     const size_t dst = (c * chip_col_stride + row_off) * cb, src = c * e->slot_rows * cb;
                     const size_t own = rows - ((tail != 0 && c >= tail) ? 1 : 0);
                     if (own == 0) continue;
-                    he = hipMemcpyAsync(static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
-                                        own * cb, hipMemcpyDeviceToHost, e->copy_stream);
+                    he = d2h(reg_cd, static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
+                             own * cb, e->copy_stream);
                     if (he == hipSuccess)
-                        he = hipMemcpyAsync(static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
-                                            own * cb, hipMemcpyDeviceToHost, e->copy_stream);
+                        he = d2h(reg_cs, static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
+                                 own * cb, e->copy_stream);
                 }
                 if (he != hipSuccess) { fail("D2H chip columns"); break; }
             }
@@ -649,9 +670,7 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         if ((he = hipStreamSynchronize(e->copy_stream)) != hipSuccess) { fail("sync copy stream"); break; }
     } while (0);
     if (rc != HSW_OK) { (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->copy_stream); }
-    if (reg_gate) (void)hipHostUnregister(reg_gate);
-    if (reg_cd) (void)hipHostUnregister(reg_cd);
-    if (reg_cs) (void)hipHostUnregister(reg_cs);
+    reg_gate.close(); reg_cd.close(); reg_cs.close();
     (void)hipFree(d_blocks); (void)hipFree(d_pre); (void)hipFree(d_next);
     return rc;
 }

@@ -55,6 +55,7 @@ struct hsw_engine {
     uint64_t verify_checks_per_block = 0;
     int verify_slices = 0;               // workgroups per block in hsw_verify_kernel; 0 = default
     hsw::VerifyReport *d_report = nullptr;
+    hsw_launch_info last_launch{};       // hsw_last_launch
 };
 
 inline int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSuccess) {

@@ -231,5 +231,13 @@ class WitnessEngine:
         self._ok(self.lib.hsw_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def last_launch(self):
+        """hsw_last_launch: the expansion kernel instantiation and work split of the most recent launch."""
+        li = N.LaunchInfo()
+        self._ok(self.lib.hsw_last_launch(self.h, C.byref(li)))
+        d = li.as_dict()
+        d["kernel"] = li.kernel_name()
+        return d
+
     def synchronize(self):
         self._ok(self.lib.hsw_engine_synchronize(self.h))

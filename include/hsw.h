@@ -74,9 +74,10 @@ extern "C" {
 
 #define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only: pin the caller's output buffers
                                       (hipHostRegister) for the duration of the call.  Registration is by
-                                      whole pages, so only buffers of at least 1 MiB whose pages no other
-                                      host buffer of the call touches are pinned, all of them or none;
-                                      otherwise the call proceeds with ordinary pageable copies. */
+                                      whole pages, so only the page INTERIOR of each buffer is pinned -- the
+                                      pages it owns entirely, whatever allocator it came from -- and the
+                                      copies are cut at that boundary; the <= 2 edge fragments (< 4 KiB
+                                      each) and buffers below 64 KiB take ordinary pageable copies. */
 
 #define HSW_CELL_BYTES         32u
 
@@ -330,6 +331,24 @@ int hsw_set_timing(hsw_engine *e, int enabled);
 
 /* The stream / device an engine was created on. */
 int hsw_engine_stream(const hsw_engine *e, void **hip_stream, int *device);
+
+/* What the most recent expansion launch of this engine was: the kernel instantiation
+ * hsw_expand_kernel<limbs, tile_cells, tile_rows, repr, internals> and its work split.  Lets a
+ * measurement name the kernel it timed instead of assuming one (bench.py roofline.kernel). */
+typedef struct hsw_launch_info {
+    uint32_t limbs;        /* 16 / num_bits_lookup */
+    uint32_t tile_cells;   /* cells per tile row = contiguous run of one unit */
+    uint32_t tile_rows;    /* units one wave expands per phase */
+    uint32_t repr;         /* 0 canonical, 1 Montgomery, 2 compact (8-byte cells) */
+    uint32_t internals;    /* engine mode HSW_MODE_HALO2_INTERNALS */
+    uint32_t parts;        /* waves per block */
+    uint32_t split;        /* 0: every wave takes a share of every phase; 1: one phase program per wave;
+                              2: one sub-unit program per wave (tiny batches) */
+    uint32_t reserved_;
+    uint64_t n_blocks;     /* blocks of that launch */
+    uint64_t grid;         /* workgroups (= waves) of that launch */
+} hsw_launch_info;
+int hsw_last_launch(const hsw_engine *e, hsw_launch_info *out);
 
 /* ------------------------------------------------------------------------
  * Gadget front-end: the host side of Sha256DynamicConfig::digest

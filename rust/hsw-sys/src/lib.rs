@@ -68,6 +68,22 @@ pub struct hsw_pack_plan {
     pub end_row: u64,
 }
 
+/// `hsw_last_launch`: the kernel instantiation and work split of the most recent expansion launch.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct hsw_launch_info {
+    pub limbs: u32,
+    pub tile_cells: u32,
+    pub tile_rows: u32,
+    pub repr: u32,
+    pub internals: u32,
+    pub parts: u32,
+    pub split: u32,
+    pub reserved_: u32,
+    pub n_blocks: u64,
+    pub grid: u64,
+}
+
 #[repr(C)]
 pub struct hsw_witness_args {
     pub d_blocks: *const u8,
@@ -247,6 +263,7 @@ extern "C" {
     pub fn hsw_engine_synchronize(e: *mut hsw_engine) -> c_int;
     pub fn hsw_engine_stream(e: *const hsw_engine, hip_stream: *mut *mut c_void, device: *mut c_int) -> c_int;
     pub fn hsw_engine_set_option(e: *mut hsw_engine, name: *const c_char, value: i64) -> c_int;
+    pub fn hsw_last_launch(e: *const hsw_engine, out: *mut hsw_launch_info) -> c_int;
 
     /// Replaces the block loop of reference src/lib.rs:180-238 over src/compression.rs:19-25.
     pub fn hsw_witness_blocks(e: *mut hsw_engine, d_blocks: *const u8, d_pre_states: *const u32,

@@ -414,6 +414,52 @@ def test_host_register_with_small_heap_buffers(engine_factory, oracle, hsw):
         assert np.array_equal(got["next_states"], ref["next_states"])
 
 
+@pytest.mark.parametrize("flags", [0, 16])      # 32-byte cells / HSW_REPR_COMPACT64
+def test_host_register_pins_the_page_interior_only(engine_factory, oracle, hsw, flags):
+    """The registering branch of HSW_HOST_REGISTER: the three output buffers (each far above a page) are cut
+    at odd, non-page offsets out of ONE larger array, back to back with 64-byte guards, so every buffer's
+    first and last page is shared with a neighbour (the layout of an arena / Rust Vec slices).  Only whole
+    pages inside a buffer may be pinned and no copy may run across the edge of a registered range: the
+    streams must be right and the guards untouched."""
+    N = hsw._native
+    eng = engine_factory(8, 2)
+    n = 8
+    blocks, pre = _rand_inputs(n, 777)
+    w = 1 if flags else 4
+    rows = eng.chip_rows(0, n)
+    sizes = [n * eng.G * w, 2 * rows * w, 2 * rows * w]          # u64 words: gate, dense, spread
+    assert min(sizes) * 8 >= 256 * 1024
+    GUARD = 8                                                     # u64 words
+    arena = np.full(sum(sizes) + GUARD * 4 + 1024, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+    base = (-(arena.ctypes.data // 8)) % 512 + 37 * 2             # 592 bytes past a page boundary (16-byte aligned)
+    views, off = [], base
+    for s in sizes:
+        views.append(arena[off:off + s])
+        assert views[-1].ctypes.data % 4096 not in (0,) and views[-1].ctypes.data % 16 == 0
+        off += s + GUARD
+    gate, dense, spread = views
+    nxt = np.zeros((n, 8), dtype=np.uint32)
+    for rep in range(2):                                          # twice: register / unregister must be repeatable
+        rc = eng.lib.hsw_witness_blocks_host(
+            eng.h, blocks.ctypes.data, pre.ctypes.data, n, 0, gate.ctypes.data, dense.ctypes.data,
+            spread.ctypes.data, rows, nxt.ctypes.data, flags | N.HSW_HOST_REGISTER)
+        assert rc == 0, eng.lib.hsw_last_error(eng.h)
+    ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, pre, cursor0=0)
+    if flags:
+        eg, ed, es = _compact_expected(oracle, hsw, ref, eng.shape, n)
+    else:
+        eg, ed, es = ref["gate"], ref["dense"], ref["spread"]
+    assert np.array_equal(gate.reshape(eg.shape), eg)
+    assert np.array_equal(dense.reshape(ed.shape), ed) and np.array_equal(spread.reshape(es.shape), es)
+    assert np.array_equal(nxt, ref["next_states"])
+    mask = np.ones(arena.shape, dtype=bool)
+    off = base
+    for s in sizes:
+        mask[off:off + s] = False
+        off += s + GUARD
+    assert (arena[mask] == 0xA5A5A5A5A5A5A5A5).all()             # nothing outside the three buffers was written
+
+
 def test_hip_graph_capture_and_replay(hsw, oracle):
     """The launch path does no allocation / synchronization, so chain + expand can
     be captured into a HIP graph and replayed on new inputs (launch-bound small
