@@ -71,8 +71,17 @@ class LaunchInfo(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved_"}
 
     def kernel_name(self):
+        if self.split == 2:
+            return "hsw::hsw_small_kernel<%d, %d, %s>" % (self.limbs, self.repr, "true" if self.internals else "false")
         return "hsw::hsw_expand_kernel<%d, %d, %d, %d, %s>" % (self.limbs, self.tile_cells, self.tile_rows, self.repr,
                                                               "true" if self.internals else "false")
+
+
+class DigestsArgs(C.Structure):
+    """hsw_digests_args (descs: pointer to FrameDesc, declared below -> void pointer here)."""
+    _fields_ = [("blocks", WitnessArgs), ("descs", C.c_void_p), ("n_digests", C.c_size_t), ("d_blocks0", C.c_void_p),
+                ("d_pre_states0", C.c_void_p), ("d_next_states0", C.c_void_p), ("d_gate0", C.c_void_p),
+                ("d_lookup0", C.c_void_p), ("frame_pack", C.POINTER(PackPlan)), ("host_next_states", C.c_void_p)]
 
 
 class FrameShape(C.Structure):
@@ -146,7 +155,7 @@ SYMBOLS = (
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
-    "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch",
+    "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
 )
 
 

@@ -269,7 +269,7 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
         return HSW_OK;
     }
     if (std::strcmp(name, "split") == 0) {
-        if (value < -1 || value > 1) return set_err(e, HSW_ERR_INVALID_ARG, "split must be -1 (auto), 0 or 1");
+        if (value < -1 || value > 2) return set_err(e, HSW_ERR_INVALID_ARG, "split must be -1 (auto), 0, 1 or 2");
         e->split = (int)value;
         return HSW_OK;
     }
@@ -320,6 +320,23 @@ int hsw_witness_blocks(hsw_engine *e, const uint8_t *d_blocks, const uint32_t *d
 } HSW_NO_UNWIND
 
 int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
+    return hsw_witness_blocks_impl(e, args, nullptr, nullptr);
+} HSW_NO_UNWIND
+
+}  // extern "C"
+
+// The small-batch kernel (hsw_small.hpp) takes a launch when the table is the reference's 8-bit one and the
+// batch is tiny (or the "split" option asks for it); everything else goes to hsw_expand_kernel.
+bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks) {
+    if (e->limbs != 2) return false;
+    if (e->split == 2) return true;
+    return e->split < 0 && e->parts == 0 && e->tile == 0 && n_blocks <= 32;
+}
+
+// hsw_witness_blocks_ex, plus (small-batch launches only) the digest frames written by waves of the same
+// launch and a second copy of the next states in pinned host memory.
+int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
+                            uint32_t *host_next_states) {
     if (!e || !args) return HSW_ERR_INVALID_ARG;
     const uint8_t *d_blocks = args->d_blocks;
     const uint32_t *d_pre_states = args->d_pre_states;
@@ -368,6 +385,8 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
         if (n_blocks > ((size_t)1 << 20))
             return set_err(e, HSW_ERR_UNSUPPORTED, "more than 2^20 blocks in one framed call");
     }
+    if ((frames || host_next_states) && !hsw_small_eligible(e, n_blocks))
+        return set_err(e, HSW_ERR_INVALID_ARG, "frames / host next states ride on small-batch launches only");
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
 
@@ -406,9 +425,10 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
         p.frame_lookups = args->frame_lookups;
         const int tile = choose_tile(e, flags);
         p.parts = (uint32_t)choose_parts(e, n_blocks, tile, flags);
-        // tiny batches are latency-bound: 32 waves per block, each running ONE phase program (all of
-        // them resident at once; measured better up to 32 blocks); only where no explicit split of the work was asked for
-        if (e->limbs == 2 && (e->split == 1 || (e->split < 0 && e->parts == 0 && n_blocks <= 32))) {
+        // tiny batches are latency-bound: the small-batch kernel (37 waves per block, one sub-unit program
+        // each; hsw_small.hpp).  "split" = 1 keeps the older one-phase-per-wave mode of hsw_expand_kernel.
+        const bool small = hsw_small_eligible(e, n_blocks);
+        if (!small && e->limbs == 2 && e->split == 1) {
             p.parts = 32;
             p.flags |= hsw::HSW_K_SPLIT;
         }
@@ -433,6 +453,18 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
                 p.chip_spread = static_cast<uint8_t *>(d_chip_spread) + (size_t)row_shift * cb;
             }
         }
+        if (small) {
+            p.next_states_host = host_next_states ? host_next_states + 8 * done : nullptr;
+            he = hsw::launch_small(p, done == 0 ? frames : nullptr, e->limbs, e->stream);
+            if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_small_kernel", he);
+            hsw_launch_info &li = e->last_launch;
+            li.limbs = 2; li.tile_cells = 128; li.tile_rows = 16;
+            li.repr = (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
+            li.internals = e->mode == HSW_MODE_HALO2_INTERNALS ? 1u : 0u;
+            li.parts = hsw::HSW_SMALL_WAVES_PER_BLOCK; li.split = 2; li.n_blocks = n;
+            li.grid = (uint64_t)n * hsw::HSW_SMALL_WAVES_PER_BLOCK + ((done == 0 && frames) ? (uint64_t)frames->n_frames * (frames->state_waves + frames->byte_waves) : 0);
+            continue;
+        }
         he = hsw::launch_expand(p, e->limbs, tile, e->stream);
         if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_expand_kernel", he);
         {
@@ -455,7 +487,9 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
         e->timed = true;
     }
     return HSW_OK;
-} HSW_NO_UNWIND
+}
+
+extern "C" {
 
 int hsw_gate_tape(const hsw_shape *shape, uint8_t *lens_out, size_t cap, size_t *n_calls) try {
     if (!shape || shape->limbs_per_spread == 0) return HSW_ERR_INVALID_ARG;

@@ -5,6 +5,7 @@
 
 #include "hsw_engine.hpp"
 #include "hsw_fr.hpp"
+#include "hsw_frame.hpp"
 #include "hsw_nounwind.hpp"
 #include "hsw_kernels.h"
 #include "hsw_structure.hpp"
@@ -360,28 +361,10 @@ static int ensure_inv_table(hsw_engine *e, size_t n) {
     return HSW_OK;
 }
 
-int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
-                       const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
-                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags) try {
-    if (!e) return HSW_ERR_INVALID_ARG;
-    if (n == 0) return HSW_OK;
-    if (!descs || !d_blocks || !d_pre_states || !d_next_states || !d_gate)
-        return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
-    if (e->mode != HSW_MODE_HALO2_INTERNALS)
-        return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
-    if (flags & ~HSW_REPR_MASK) return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
-    if (flags & HSW_REPR_COMPACT64)
-        return set_err(e, HSW_ERR_UNSUPPORTED, "digest frames hold full-width cells: no HSW_REPR_COMPACT64");
-    if (((uintptr_t)d_gate & 15u) || ((uintptr_t)d_lookup & 15u))
-        return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
-    if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
-    hsw::FrameBreaks brk{};
-    if (pack) {
-        brk.n = pack->n_breaks;
-        for (uint32_t k = 0; k < pack->n_breaks; k++) { brk.cell[k] = pack->break_cell[k]; brk.gap[k] = pack->break_gap[k]; }
-    }
-    DeviceScope ds(e->device);
-    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+// Checks n frame descriptors and stages them in one of the engine's pinned, device-mapped descriptor
+// buffers (the kernel reads them in place: no H2D copy).  The caller records slot->done after its launch.
+static int stage_frame_descs(hsw_engine *e, const hsw_frame_desc *descs, size_t n, hsw::FrameDesc **d_descs,
+                             size_t *max_blocks_out, hsw_engine::FrameSlot **slot_out) {
     hipError_t he;
     hsw_engine::FrameSlot &slot = e->frame_slot[e->frame_next++ & 3u];
     if (slot.inflight) {                      // the launch that last used this slot must have read it
@@ -420,18 +403,122 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
     }
     int rc = ensure_inv_table(e, max_blocks + 1);
     if (rc != HSW_OK) return rc;
-    hsw::FrameDesc *d_descs = nullptr;
-    he = hipHostGetDevicePointer((void **)&d_descs, slot.h, 0);
+    he = hipHostGetDevicePointer((void **)d_descs, slot.h, 0);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipHostGetDevicePointer", he);
+    *max_blocks_out = max_blocks;
+    *slot_out = &slot;
+    return HSW_OK;
+}
+
+static int check_frame_args(hsw_engine *e, const hsw_frame_desc *descs, const uint8_t *d_blocks,
+                            const uint32_t *d_pre_states, void *d_gate, void *d_lookup, const hsw_pack_plan *pack,
+                            uint32_t flags, hsw::FrameBreaks *brk) {
+    if (!descs || !d_blocks || !d_pre_states || !d_gate) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    if (e->mode != HSW_MODE_HALO2_INTERNALS)
+        return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
+    if (flags & ~HSW_REPR_MASK) return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
+    if (flags & HSW_REPR_COMPACT64)
+        return set_err(e, HSW_ERR_UNSUPPORTED, "digest frames hold full-width cells: no HSW_REPR_COMPACT64");
+    if (((uintptr_t)d_gate & 15u) || ((uintptr_t)d_lookup & 15u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
+    if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    *brk = hsw::FrameBreaks{};
+    if (pack) {
+        brk->n = pack->n_breaks;
+        for (uint32_t k = 0; k < pack->n_breaks; k++) { brk->cell[k] = pack->break_cell[k]; brk->gap[k] = pack->break_gap[k]; }
+    }
+    return HSW_OK;
+}
+
+int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, const uint8_t *d_blocks,
+                       const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
+                       void *d_lookup, const hsw_pack_plan *pack, uint32_t flags) try {
+    if (!e) return HSW_ERR_INVALID_ARG;
+    if (n == 0) return HSW_OK;
+    if (!d_next_states) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    hsw::FrameBreaks brk{};
+    int rc = check_frame_args(e, descs, d_blocks, d_pre_states, d_gate, d_lookup, pack, flags, &brk);
+    if (rc != HSW_OK) return rc;
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    hsw::FrameDesc *d_descs = nullptr;
+    size_t max_blocks = 0;
+    hsw_engine::FrameSlot *slot = nullptr;
+    rc = stage_frame_descs(e, descs, n, &d_descs, &max_blocks, &slot);
+    if (rc != HSW_OK) return rc;
     const bool mont = (flags & HSW_REPR_MONTGOMERY) != 0;
-    he = hsw::launch_frames(d_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
+    hipError_t he = hsw::launch_frames(d_descs, n, d_blocks, d_pre_states, d_next_states, e->d_inv_tbl[mont ? 1 : 0],
                             d_gate, d_lookup, brk,
                             /* workgroups per digest: one per 4 blocks (256 input bytes each), at most 64 */
                             (unsigned)(max_blocks / 4 < 1 ? 1 : (max_blocks / 4 > 64 ? 64 : max_blocks / 4)), mont, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_frame_kernel", he);
-    he = hipEventRecord(slot.done, e->stream);
+    he = hipEventRecord(slot->done, e->stream);
     if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
-    slot.inflight = true;
+    slot->inflight = true;
+    return HSW_OK;
+} HSW_NO_UNWIND
+
+int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
+    if (!e || !a) return HSW_ERR_INVALID_ARG;
+    const hsw_witness_args &b = a->blocks;
+    if (a->n_digests == 0 || b.n_blocks == 0) return HSW_OK;
+    if (!a->d_next_states0) return set_err(e, HSW_ERR_INVALID_ARG, "null pointer");
+    hsw::FrameBreaks brk{};
+    int rc = check_frame_args(e, a->descs, a->d_blocks0, a->d_pre_states0, a->d_gate0, a->d_lookup0, a->frame_pack,
+                              b.flags & HSW_REPR_MASK, &brk);
+    if (rc != HSW_OK) return rc;
+    // the block streams of the call must be exactly the blocks of its digests, in order, with the frames
+    // of equally sized digests in between (what frame_every describes)
+    size_t sum = 0;
+    for (size_t i = 0; i < a->n_digests; i++) {
+        if (a->descs[i].n_blocks != a->descs[0].n_blocks)
+            return set_err(e, HSW_ERR_INVALID_ARG, "one call = equally sized digests");
+        sum += a->descs[i].n_blocks;
+    }
+    if (sum != b.n_blocks || (a->n_digests > 1 && b.frame_every != a->descs[0].n_blocks))
+        return set_err(e, HSW_ERR_INVALID_ARG, "blocks.n_blocks / frame_every do not match the digests");
+    DeviceScope ds(e->device);
+    if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (!hsw_small_eligible(e, b.n_blocks)) {
+        // two launches: the expansion, then the frames from the next states it left in HBM
+        rc = hsw_witness_blocks_ex(e, &b);
+        if (rc == HSW_OK)
+            rc = hsw_witness_frames(e, a->descs, a->n_digests, a->d_blocks0, a->d_pre_states0, a->d_next_states0,
+                                    a->d_gate0, a->d_lookup0, a->frame_pack, b.flags & HSW_REPR_MASK);
+        if (rc == HSW_OK && a->host_next_states && b.d_next_states) {
+            hipError_t he = hipMemcpyAsync(a->host_next_states, b.d_next_states, b.n_blocks * 32, hipMemcpyDeviceToHost, e->stream);
+            if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "D2H next states", he);
+        }
+        return rc;
+    }
+    // ONE launch: frame waves ride on the small-batch kernel's grid
+    hsw::FrameDesc *d_descs = nullptr;
+    size_t max_blocks = 0;
+    hsw_engine::FrameSlot *slot = nullptr;
+    rc = stage_frame_descs(e, a->descs, a->n_digests, &d_descs, &max_blocks, &slot);
+    if (rc != HSW_OK) return rc;
+    hsw::SmallFrames fr{};
+    fr.descs = d_descs;
+    fr.inv_tbl = e->d_inv_tbl[(b.flags & HSW_REPR_MONTGOMERY) ? 1 : 0];
+    fr.blocks0 = a->d_blocks0;
+    fr.pre0 = a->d_pre_states0;
+    fr.gate0 = a->d_gate0;
+    fr.lookup0 = a->d_lookup0;
+    fr.n_frames = (uint32_t)a->n_digests;
+    fr.byte_waves = (uint32_t)(max_blocks > 32 ? 32 : max_blocks);                  // one wave per 64 input bytes
+    fr.state_waves = (uint32_t)((9 * (max_blocks + 1) + 63) / 64 < 4 ? (9 * (max_blocks + 1) + 63) / 64 : 4) + 1;
+    fr.d0 = *slot->h;                                                                // (stage_frame_descs converted it)
+    fr.brk = brk;
+    uint32_t *host_next = nullptr;
+    if (a->host_next_states) {
+        hipError_t he = hipHostGetDevicePointer((void **)&host_next, a->host_next_states, 0);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_INVALID_ARG, "host_next_states is not pinned, device-mapped host memory (hsw_host_alloc)", he);
+    }
+    rc = hsw_witness_blocks_impl(e, &b, &fr, host_next);
+    if (rc != HSW_OK) return rc;
+    hipError_t he = hipEventRecord(slot->done, e->stream);
+    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
+    slot->inflight = true;
     return HSW_OK;
 } HSW_NO_UNWIND
 

@@ -20,7 +20,8 @@ struct hsw_engine {
     hsw_shape shape{};
     int limbs = 2;
     int parts = 0;             // waves per block; 0 = choose from the batch size
-    int split = -1;            // one phase per wave (32 waves per block): -1 = for tiny batches, 0 = never, 1 = always
+    int split = -1;            // -1 = small-batch kernel for <= 32 blocks, 0 = never, 1 = one phase per wave (32 waves per
+                               // block) in hsw_expand_kernel, 2 = small-batch kernel always
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
     size_t chunk_blocks = (size_t)1 << 20;   // blocks per launch (longer batches are consecutive launches)
     uint32_t mode = HSW_MODE_DEFAULT;
@@ -69,6 +70,11 @@ inline int set_err(hsw_engine *e, int status, const char *what, hipError_t he = 
     }
     return status;
 }
+
+namespace hsw { struct SmallFrames; }
+bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks);
+int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
+                            uint32_t *host_next_states);
 
 // Makes the engine's device current for the scope of one call.
 struct DeviceScope {

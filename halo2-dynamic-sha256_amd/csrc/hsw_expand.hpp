@@ -77,6 +77,15 @@ static __device__ __constant__ u32 IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef37
 
 #define DEV __device__ __forceinline__
 
+// Tuning aid (tools/latency_probe): with -DHSW_STAMPS every wave records the 100 MHz wall clock at its
+// phase boundaries.  Never defined in the product build.
+#ifdef HSW_STAMPS
+__device__ unsigned long long *g_hsw_stamps = nullptr;
+#define HSW_STAMP(i) do { if (threadIdx.x == 0 && g_hsw_stamps) g_hsw_stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define HSW_STAMP(i) do { } while (0)
+#endif
+
 DEV u32 rotr32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 
 // dense 16 bits -> 32 bits with bit i at position 2i (the "spread" form,
@@ -183,7 +192,7 @@ DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
 // ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
 // REPR: 0 = canonical 32-byte cells, 1 = Montgomery 32-byte cells, 2 = compact 8-byte cells
 // (low 64 bits; the negation cells hold x where the field value is -x -- hsw.h HSW_REPR_COMPACT64).
-template <int T, int R, int REPR_, bool RC_>
+template <int T, int R, int REPR_, bool RC_, bool NO_REALIGN_ = false>
 struct Em {
     static constexpr int TILE = T, ROWS = R;
     static constexpr int REPR = REPR_;
@@ -193,7 +202,9 @@ struct Em {
     // Realigned write-out (flush_tile).  Free for the HBM-bound canonical kernels; the Montgomery kernels
     // are issue-bound and pay ~4 % for it even on aligned streams, so they realign only in internals mode,
     // where misaligned streams are the rule (digest frames, column images); compact cells never do.
-    static constexpr bool REALIGN = REPR_ == 0 || (REPR_ == 1 && RC_);
+    // (NO_REALIGN_: the small-batch kernel of hsw_small.hpp -- latency-bound launches, rows are sub-units whose
+    //  tails and heads are not neighbours in the stream.)
+    static constexpr bool REALIGN = !NO_REALIGN_ && (REPR_ == 0 || (REPR_ == 1 && RC_));
     static constexpr int STRIDE = REALIGN ? T + 3 : T + 1;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
     u64 *row0;         // this lane's tile row (LDS), column 0
     u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
@@ -303,7 +314,54 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
         auto row_of = [&](u32 i, u32 per_cell) -> u32 {
             return wide_rows ? i / ((ncells + 4u) * per_cell) : i / ((ncells ? ncells : 1u) * per_cell);
         };
-        if constexpr (EM::COMPACT) {
+        // an unskewed partial flush without column breaks (every flush of the small-batch kernel's last
+        // tile): rows x [0, ncells) with constant strides, no division per piece
+        const bool plain_partial = !FULL && !packed && skew == 0u;
+        if (plain_partial) {
+            const u32 row_bytes = em.unit_cells * (EM::COMPACT ? 8u : 32u);
+            if constexpr (EM::COMPACT) {
+                u32 off = (em.cell_base + seg + lane) * 8u;
+                const u64 *src = em.tile + lane;
+                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes)
+                    for (u32 q = 0; lane + q < ncells; q += 64) store8(base, off + q * 8u, src[q]);
+            } else if constexpr (EM::MONT) {
+                u32 off = (em.cell_base + seg + lane) * 32u;
+                const u64 *src = em.tile + lane;
+                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes)
+                    for (u32 q = 0; lane + q < ncells; q += 64) {
+                        const u64 v = src[q];
+                        Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
+                        if (any_neg) {
+                            if (is_neg(lane + q) && v != 0ull) m = fe_neg_nonzero(m);
+                        }
+                        store16(base, off + q * 32u, make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]));
+                        store16(base, off + q * 32u + 16u, make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]));
+                    }
+            } else {
+                // like the full-tile path below: all T / 32 LDS reads of a row first (columns past ncells hold
+                // stale cells of the same row -- read, never stored), then the stores
+                const u32 h = lane & 1u, p0 = lane >> 1;
+                const u64 *src = em.tile + p0;
+                u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
+                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+                    u64 vv[T / 32];
+#pragma unroll
+                    for (int k = 0; k < T / 32; k++) vv[k] = src[32 * k];
+#pragma unroll
+                    for (int k = 0; k < T / 32; k++) {
+                        const u64 v = vv[k];
+                        const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+                        uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
+                        if (any_neg) {
+                            if (is_neg(p0 + 32u * (u32)k) && v != 0ull)
+                                o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
+                                      : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
+                        }
+                        if (p0 + 32u * (u32)k < ncells) store16(base, off + 1024u * (u32)k, o);
+                    }
+                }
+            }
+        } else if constexpr (EM::COMPACT) {
             // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
             // Negation cells keep x (their positions are static: hsw_neg_cells).  (skew is always 0 here)
 #pragma unroll 4
@@ -770,16 +828,35 @@ DEV auto sigma_generic(C c0, EM &em, u32 x, u32 &out) {
     return g_mul_add(c21, em, hi_even, 1u << 16, lo_even, out);   // :874-879
 }
 
-// ch (compression.rs:297-405); x, y, z are the dense words e, f, g
+// ch (compression.rs:297-405); x, y, z are the dense words e, f, g.  In two halves so that the small-batch
+// kernel (hsw_small.hpp) can give them to different waves: A = the sums, the negations, the eight even / odd
+// witnesses and the re-checks of p; B = the re-checks of q and the result.
+struct ChVals {
+    u32 x_lo, x_hi, y_lo, y_hi, z_lo, z_hi;
+    u32 p_lo_even, p_lo_odd, p_hi_even, p_hi_odd, q_lo_even, q_lo_odd, q_hi_even, q_hi_odd;
+};
+DEV ChVals ch_values(u32 x, u32 y, u32 z) {
+    ChVals v;
+    v.x_lo = spread16(x); v.x_hi = spread16(x >> 16);
+    v.y_lo = spread16(y); v.y_hi = spread16(y >> 16);
+    v.z_lo = spread16(z); v.z_hi = spread16(z >> 16);
+    const u32 MASK_EVEN_32 = 0x55555555u;
+    const u32 p_lo = v.x_lo + v.y_lo, p_hi = v.x_hi + v.y_hi;                         // :309-318
+    const u32 q_lo = MASK_EVEN_32 - v.x_lo + v.z_lo, q_hi = MASK_EVEN_32 - v.x_hi + v.z_hi;   // :319-335 (values < 2^32)
+    // :336-343 four even/odd splits before any re-check
+    v.p_lo_even = even_bits(p_lo); v.p_lo_odd = even_bits(p_lo >> 1);
+    v.p_hi_even = even_bits(p_hi); v.p_hi_odd = even_bits(p_hi >> 1);
+    v.q_lo_even = even_bits(q_lo); v.q_lo_odd = even_bits(q_lo >> 1);
+    v.q_hi_even = even_bits(q_hi); v.q_hi_odd = even_bits(q_hi >> 1);
+    return v;
+}
 template <int L, class EM, class C>
-DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
-    const u32 x_lo = spread16(x), x_hi = spread16(x >> 16);
-    const u32 y_lo = spread16(y), y_hi = spread16(y >> 16);
-    const u32 z_lo = spread16(z), z_hi = spread16(z >> 16);
+DEV auto ch_part_a(C c0, EM &em, const ChVals &v) {
+    const u32 x_lo = v.x_lo, x_hi = v.x_hi;
     const u32 MASK_EVEN_32 = 0x55555555u;
     u64 p_lo, p_hi, q_lo, q_hi;
-    auto c1 = g_add(c0, em, x_lo, y_lo, p_lo);               // :309-313
-    auto c2 = g_add(c1, em, x_hi, y_hi, p_hi);               // :314-318
+    auto c1 = g_add(c0, em, x_lo, v.y_lo, p_lo);             // :309-313
+    auto c2 = g_add(c1, em, x_hi, v.y_hi, p_hi);             // :314-318
     // neg: [a, -a, 1, 0]                                       :320-321
     auto c3 = emit(c2, em, x_lo);
     auto c4 = emit_neg(c3, em, x_lo);
@@ -795,36 +872,40 @@ DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
     auto c12 = emit_neg(c11, em, x_lo);
     auto c13 = emit(c12, em, 1);
     auto c14 = emit(c13, em, t_lo);
-    auto c15 = g_add(c14, em, t_lo, z_lo, q_lo);
+    auto c15 = g_add(c14, em, t_lo, v.z_lo, q_lo);
     auto c16 = emit(c15, em, MASK_EVEN_32);
     auto c17 = emit_neg(c16, em, x_hi);
     auto c18 = emit(c17, em, 1);
     auto c19 = emit(c18, em, t_hi);
-    auto c20 = g_add(c19, em, t_hi, z_hi, q_hi);
+    auto c20 = g_add(c19, em, t_hi, v.z_hi, q_hi);
     // :336-343 four even/odd splits before any re-check
-    const u32 p_lo_even = even_bits((u32)p_lo), p_lo_odd = even_bits((u32)p_lo >> 1);
-    const u32 p_hi_even = even_bits((u32)p_hi), p_hi_odd = even_bits((u32)p_hi >> 1);
-    const u32 q_lo_even = even_bits((u32)q_lo), q_lo_odd = even_bits((u32)q_lo >> 1);
-    const u32 q_hi_even = even_bits((u32)q_hi), q_hi_odd = even_bits((u32)q_hi >> 1);
-    auto c21 = g_lw(c20, em, p_lo_even);
-    auto c22 = g_lw(c21, em, p_lo_odd);
-    auto c23 = g_lw(c22, em, p_hi_even);
-    auto c24 = g_lw(c23, em, p_hi_odd);
-    auto c25 = g_lw(c24, em, q_lo_even);
-    auto c26 = g_lw(c25, em, q_lo_odd);
-    auto c27 = g_lw(c26, em, q_hi_even);
-    auto c28 = g_lw(c27, em, q_hi_odd);
-    lookup16(em, p_lo_even); lookup16(em, p_lo_odd); lookup16(em, p_hi_even); lookup16(em, p_hi_odd);
-    lookup16(em, q_lo_even); lookup16(em, q_lo_odd); lookup16(em, q_hi_even); lookup16(em, q_hi_odd);
-    auto c29 = recheck_even_odd<L>(c28, em, p_lo_even, p_lo_odd);     // :344-354
-    auto c30 = recheck_even_odd<L>(c29, em, p_hi_even, p_hi_odd);     // :355-365
-    auto c31 = recheck_even_odd<L>(c30, em, q_lo_even, q_lo_odd);     // :366-376
-    auto c32 = recheck_even_odd<L>(c31, em, q_hi_even, q_hi_odd);     // :377-387
+    auto c21 = g_lw(c20, em, v.p_lo_even);
+    auto c22 = g_lw(c21, em, v.p_lo_odd);
+    auto c23 = g_lw(c22, em, v.p_hi_even);
+    auto c24 = g_lw(c23, em, v.p_hi_odd);
+    auto c25 = g_lw(c24, em, v.q_lo_even);
+    auto c26 = g_lw(c25, em, v.q_lo_odd);
+    auto c27 = g_lw(c26, em, v.q_hi_even);
+    auto c28 = g_lw(c27, em, v.q_hi_odd);
+    lookup16(em, v.p_lo_even); lookup16(em, v.p_lo_odd); lookup16(em, v.p_hi_even); lookup16(em, v.p_hi_odd);
+    lookup16(em, v.q_lo_even); lookup16(em, v.q_lo_odd); lookup16(em, v.q_hi_even); lookup16(em, v.q_hi_odd);
+    auto c29 = recheck_even_odd<L>(c28, em, v.p_lo_even, v.p_lo_odd);     // :344-354
+    return recheck_even_odd<L>(c29, em, v.p_hi_even, v.p_hi_odd);         // :355-365
+}
+template <int L, class EM, class C>
+DEV auto ch_part_b(C c30, EM &em, const ChVals &v, u32 &out) {
+    auto c31 = recheck_even_odd<L>(c30, em, v.q_lo_even, v.q_lo_odd);     // :366-376
+    auto c32 = recheck_even_odd<L>(c31, em, v.q_hi_even, v.q_hi_odd);     // :377-387
     u64 out_lo, out_hi;
-    auto c33 = g_add(c32, em, p_lo_odd, q_lo_odd, out_lo);   // :388-392
-    auto c34 = g_add(c33, em, p_hi_odd, q_hi_odd, out_hi);   // :393-397
+    auto c33 = g_add(c32, em, v.p_lo_odd, v.q_lo_odd, out_lo);   // :388-392
+    auto c34 = g_add(c33, em, v.p_hi_odd, v.q_hi_odd, out_hi);   // :393-397
     out = ((u32)out_hi << 16) + (u32)out_lo;
     return g_mul_add(c34, em, out_hi, 1u << 16, out_lo, out);    // :398-403
+}
+template <int L, class EM, class C>
+DEV auto ch_gadget(C c0, EM &em, u32 x, u32 y, u32 z, u32 &out) {
+    const ChVals v = ch_values(x, y, z);
+    return ch_part_b<L>(ch_part_a<L>(c0, em, v), em, v, out);
 }
 
 // maj (compression.rs:460-519)
@@ -888,6 +969,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     __shared__ u16 s_d16[R * LY::CALLS_ROUND];    // largest phase-part: R rounds x 24 spread calls
     __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
 
+    HSW_STAMP(0);
     const u32 lane = threadIdx.x;
     const u32 parts = p.parts;                   // waves per block (power of two <= 16)
     const size_t blk = blockIdx.x / parts;
@@ -933,6 +1015,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         }
     }
     __syncthreads();
+    HSW_STAMP(1);
 
     // ---- every lane pulls the seeds of its units into registers -------------
     auto pre_word = [&](u32 i) -> u32 { return i < 4 ? sA[3 - i] : sE[7 - i]; };   // a..d = sA[3..0], e..h = sE[3..0]
@@ -952,6 +1035,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     const u32 seed_wr = sW[ur], seed_k = K256[ur];
     const u32 seed_fx = uf < 4 ? sA[67 - uf] : sE[71 - uf], seed_fy = pre_word(uf);
     __syncthreads();           // seeds are in registers: the tile may now overwrite them
+    HSW_STAMP(2);
 
     EM em;
     em.lk16 = s_lk16;
@@ -1054,6 +1138,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         auto c17 = state_to_spread<L>(c16, em, a_new);                         // :195
         phase_end<L>(c17, em, p, blk_limb0, lk_blk);
     }
+    HSW_STAMP(3);
 
     // ---- feed-forward: compression.rs:197-212, 8 units ---------------------
     if (in_phase[PH_FEED] && phase_begin(em, wp[PH_FEED], wn[PH_FEED], 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
@@ -1063,6 +1148,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
         auto c2 = mod_u32(c1, em, s, lo);
         phase_end<L>(c2, em, p, blk_limb0, lk_blk);
     }
+    HSW_STAMP(4);
 }
 
 // ------------------------------------------------------------------ launch

@@ -84,5 +84,20 @@ struct FrameBreaks {
     uint64_t gap[16];
 };
 
+// Whole-digest launches of the small-batch kernel (hsw_small.hpp): the frames are written by waves of the
+// same grid as the expansion.  Block indices in the descriptors are relative to blocks0 / pre0.
+struct SmallFrames {
+    const FrameDesc *descs;       // n_frames digests; may live in pinned, device-mapped host memory
+    const uint64_t *inv_tbl;      // k^-1 table in the output representation (launch_frames)
+    const uint8_t *blocks0;       // block bytes / pre-states the descriptors' first_block indexes
+    const uint32_t *pre0;
+    void *gate0, *lookup0;        // bases of the whole gate / lookup streams (frame cells are absolute indices)
+    uint32_t n_frames;
+    uint32_t state_waves;         // waves per digest on the cells that look at state words (they run the last block's chain)
+    uint32_t byte_waves;          // waves per digest on the input-byte cells
+    FrameBreaks brk;              // column breaks in absolute gate-stream cells
+    FrameDesc d0;                 // descs[0] by value: a single digest needs no read of host memory to get going
+};
+
 }  // namespace hsw
 #endif

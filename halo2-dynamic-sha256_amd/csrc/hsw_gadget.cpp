@@ -14,6 +14,11 @@
 #include "hsw_nounwind.hpp"
 #include "hsw_kernels.h"
 
+// library-internal entry points of hsw_api.cpp (hsw_engine.hpp)
+bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks);
+int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
+                            uint32_t *host_next_states);
+
 namespace hsw {
 
 namespace {
@@ -276,6 +281,7 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
             c->hp_next = reinterpret_cast<uint32_t *>(c->hp_blocks + nb * 96);
             c->dp_blocks = static_cast<uint8_t *>(dpin);
             c->dp_pre = reinterpret_cast<uint32_t *>(c->dp_blocks + nb * 64);
+            c->dp_next = reinterpret_cast<uint32_t *>(c->dp_blocks + nb * 96);
         }
     }
     if (he == hipSuccess) he = hipMemset(c->d_chip_dense, 0, col_bytes);
@@ -422,9 +428,14 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     DeviceScope ds(device);
     if (!ds.ok) return HSW_ERR_NO_DEVICE;
     // Up to 32 blocks the expansion reads its 96 input bytes per block straight from the pinned staging
-    // (uncached PCIe reads: cheaper than two copies for a handful of waves, not beyond); the frame kernel
-    // reads every byte on its own, so whole-digest contexts always take the copies.
-    const bool zero_copy = host_chain && !ctx.whole && batch_blocks <= 32;
+    // (uncached PCIe reads: cheaper than two copies for a handful of waves, not beyond).
+    // Tiny batches (the reference's bench circuit is ONE 16-block digest) are latency-bound: they go to the
+    // small-batch kernel, which for a whole-digest context also writes the frames -- ONE launch, inputs read
+    // in place from the pinned staging, next states written straight into pinned memory, no copy launches.
+    bool one_run = true;                       // whole-digest contexts: all digests of the batch equally sized
+    for (size_t i = 1; i < n; i++) one_run = one_run && plans[i].max_variable_round == plans[0].max_variable_round;
+    const bool small = hsw_small_eligible(ctx.engine, batch_blocks) && (!ctx.whole || one_run);
+    const bool zero_copy = host_chain && batch_blocks <= 32 && (!ctx.whole || small);
     const uint8_t *in_blocks = zero_copy ? ctx.dp_blocks : ctx.d_blocks;        // bases, indexed by absolute block
     const uint32_t *in_pre = zero_copy ? ctx.dp_pre : ctx.d_pre_states;
     const uint8_t *d_blk = in_blocks + 64 * b0;
@@ -434,6 +445,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     uint32_t *h_next = ctx.hp_next + 8 * b0;                                     // pinned: the D2H below is asynchronous
     hipError_t he = hipSuccess;
     int rc = HSW_OK;
+    bool next_in_pinned = false;               // the kernel wrote the next states into hp_next itself
     std::vector<hsw_frame_desc> frames;
     uint64_t new_gate_cursor = ctx.gate_cursor, new_lookup_cursor = ctx.lookup_cursor;
     do {
@@ -455,11 +467,17 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
             // one call covers every block of the batch; the chip cursor is the running num_limb_sum.
             // Column buffers are addressed from absolute row 0 (cursor origin of the context).
             const uint64_t row_shift = ctx.num_limb_sum / ncols;
-            rc = hsw_witness_blocks(ctx.engine, d_blk, d_pre, batch_blocks, ctx.num_limb_sum,
-                                    static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb,
-                                    static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb,
-                                    static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb,
-                                    ctx.chip_col_stride, d_next, ctx.repr_flags);
+            hsw_witness_args a{};
+            a.d_blocks = d_blk; a.d_pre_states = d_pre; a.n_blocks = batch_blocks;
+            a.spread_cursor0 = ctx.num_limb_sum;
+            a.d_gate = static_cast<uint8_t *>(ctx.d_gate) + b0 * G * cb;
+            a.d_chip_dense = static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb;
+            a.d_chip_spread = static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb;
+            a.chip_col_stride = ctx.chip_col_stride;
+            a.d_next_states = d_next;
+            a.flags = ctx.repr_flags;
+            rc = hsw_witness_blocks_impl(ctx.engine, &a, nullptr, small ? ctx.dp_next + 8 * b0 : nullptr);
+            next_in_pinned = small && rc == HSW_OK;
         } else {
             // whole-digest stream: prologue | [zero cell] | blocks | epilogue per digest (hsw_frame.hpp).
             // Consecutive digests of equal size are ONE expansion launch (the kernel skips the frame
@@ -496,6 +514,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
             ob = 0;
             for (size_t i = 0; i < n && rc == HSW_OK;) {
                 size_t j = i + 1;                            // run [i, j) of equally sized digests
+                if (small) j = n;                            // (one_run) all of them, frames included, in one launch
                 while (j < n && frames[j].n_blocks == frames[i].n_blocks) j++;
                 const size_t nb = frames[i].n_blocks, run_blocks = nb * (j - i);
                 const uint64_t cursor = ctx.num_limb_sum + (uint64_t)ob * ctx.shape.limb_calls_per_block;
@@ -526,11 +545,29 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                     }
                     a.pack = &plan;
                 }
-                rc = hsw_witness_blocks_ex(ctx.engine, &a);
+                if (small) {
+                    hsw_digests_args da{};
+                    da.blocks = a;
+                    da.descs = frames.data(); da.n_digests = n;
+                    da.d_blocks0 = in_blocks; da.d_pre_states0 = in_pre; da.d_next_states0 = ctx.d_next_states;
+                    da.d_gate0 = ctx.d_gate; da.d_lookup0 = ctx.d_lookup;
+                    hsw_pack_plan abs_plan{};
+                    abs_plan.n_breaks = (uint32_t)ctx.break_cell.size();
+                    for (size_t k = 0; k < ctx.break_cell.size(); k++) {
+                        abs_plan.break_cell[k] = ctx.break_cell[k];
+                        abs_plan.break_gap[k] = ctx.break_gap[k];
+                    }
+                    da.frame_pack = ctx.max_rows ? &abs_plan : nullptr;
+                    da.host_next_states = h_next;
+                    rc = hsw_witness_digests(ctx.engine, &da);
+                    next_in_pinned = rc == HSW_OK;
+                } else {
+                    rc = hsw_witness_blocks_ex(ctx.engine, &a);
+                }
                 ob += run_blocks;
                 i = j;
             }
-            if (rc == HSW_OK) {
+            if (rc == HSW_OK && !small) {
                 hsw_pack_plan plan{};
                 plan.n_breaks = (uint32_t)ctx.break_cell.size();
                 for (size_t k = 0; k < ctx.break_cell.size(); k++) {
@@ -543,7 +580,8 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
             if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
         }
         if (rc != HSW_OK) break;
-        if ((he = hipMemcpyAsync(h_next, d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        if (!next_in_pinned &&
+            (he = hipMemcpyAsync(h_next, d_next, batch_blocks * 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         he = hipStreamSynchronize(stream);
     } while (0);
     if (rc != HSW_OK) return rc;
@@ -883,7 +921,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) try {
                 d.zero_cell = rk.block_cell == rk.prologue_cell + fs.prologue_cells + 1 ? rk.block_cell - 1 : ~0ull;
                 blk += rk.n_blocks;
             }
-            rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), c.d_blocks, c.d_pre_states, c.d_next_states, c.d_gate,
+            rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), in_blocks, in_pre, c.d_next_states, c.d_gate,
                                    c.d_lookup, c.max_rows ? &abs_plan : nullptr, b.repr_flags, &r);
             if (rc != HSW_OK) return rc;
             merge(r);

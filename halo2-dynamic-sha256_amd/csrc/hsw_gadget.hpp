@@ -112,7 +112,7 @@ class Context {
     uint8_t *hp_blocks = nullptr;        // host views ...
     uint32_t *hp_pre = nullptr, *hp_next = nullptr;
     uint8_t *dp_blocks = nullptr;        // ... and the device addresses of the same memory
-    uint32_t *dp_pre = nullptr;
+    uint32_t *dp_pre = nullptr, *dp_next = nullptr;
     uint32_t repr_flags = HSW_REPR_CANONICAL;
     // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
     // digest, back to back) and d_lookup the lookup-advice stream next to it

@@ -18,6 +18,7 @@ enum : uint32_t {
     HSW_K_SPLIT = 32u,       // 32 waves per block, each running one phase program (tiny batches: latency)
 };
 enum { HSW_K_MAX_BREAKS = 16 };
+enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)
 
 struct ExpandParams {
     const uint8_t *blocks;        // n_blocks * 64 bytes
@@ -41,6 +42,7 @@ struct ExpandParams {
     // frame_cells cells and the lookup stream frame_lookups cells (a digest's epilogue and the
     // next digest's prologue, written by hsw_frame_kernel); frame_every = 0: off
     uint64_t frame_every, frame_cells, frame_lookups;
+    uint32_t *next_states_host;   // small-batch kernel only: a second copy of next_states, in pinned host memory (may be null)
 };
 
 // limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count
@@ -57,6 +59,10 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 
 struct FrameDesc;   // hsw_frame.hpp
 struct FrameBreaks;
+struct SmallFrames;
+// The small-batch kernel (hsw_small.hpp; 8-bit table only): 37 waves per block, one sub-unit program each;
+// with `frames` the digest frames are written by extra waves of the same launch.
+hipError_t launch_small(const ExpandParams &p, const SmallFrames *frames, int limbs, hipStream_t stream);
 // d_inv_tbl: k^-1 mod p for k = 0..(largest n_blocks), 4 x u64 each, in the output representation
 hipError_t launch_frames(const FrameDesc *d_descs, size_t n, const uint8_t *blocks, const uint32_t *pre_states,
                          const uint32_t *next_states, const uint64_t *d_inv_tbl, void *gate, void *lookup,

@@ -448,6 +448,31 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
                        const uint32_t *d_pre_states, const uint32_t *d_next_states, void *d_gate,
                        void *d_lookup, const hsw_pack_plan *pack, uint32_t flags);
 
+/* Block streams AND frames of n equally sized digests in one call: what hsw_witness_blocks_ex (with
+ * frame_every = the digests' block count) followed by hsw_witness_frames do.  For up to 32 blocks -- the
+ * reference's own bench circuit is one 16-block digest -- it is ONE kernel launch: the frame cells are
+ * written by extra waves of the expansion's grid, which take the candidate states from the chain inputs
+ * (pre-state of block b + 1 = next state of block b) and compute the last block's output themselves, so
+ * nothing waits for the expansion.  Larger batches: the two launches above.
+ *   blocks            the block streams, exactly as for hsw_witness_blocks_ex
+ *   descs, n_digests  as for hsw_witness_frames; first_block / cell indices relative to the *0 bases
+ *   frame_pack        column breaks in absolute cells of d_gate0 (blocks.pack: relative to blocks.d_gate)
+ *   host_next_states  optional: pinned host memory (hsw_host_alloc), blocks.n_blocks * 8 words; receives a
+ *                     copy of the next states without a separate copy launch.  Valid after the stream has
+ *                     been synchronized. */
+typedef struct hsw_digests_args {
+    hsw_witness_args blocks;
+    const hsw_frame_desc *descs;
+    size_t n_digests;
+    const uint8_t *d_blocks0;
+    const uint32_t *d_pre_states0;
+    const uint32_t *d_next_states0;
+    void *d_gate0, *d_lookup0;
+    const hsw_pack_plan *frame_pack;
+    uint32_t *host_next_states;
+} hsw_digests_args;
+int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *args);
+
 typedef struct hsw_gadget hsw_gadget;   /* Sha256DynamicConfig + its Context */
 
 typedef struct hsw_hash_result {        /* AssignedHashResult (lib.rs:31-36) on values */
@@ -554,9 +579,10 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
 /* Tuning knobs (never change results).  "parts": waves per block, 0 = chosen
  * from the batch size (default), or 1, 2, 4, 8, 16.  "tile": cells per
  * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
- * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": one phase
- * program per wave, 32 waves per block -- -1 = for batches of <= 32 blocks (default), 0 = never,
- * 1 = always.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
+ * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": how tiny batches
+ * are dealt to waves -- -1 = the small-batch kernel (37 waves per block, one sub-unit program each) for
+ * batches of <= 32 blocks (default), 0 = never, 1 = one phase program per wave (32 waves per block),
+ * 2 = the small-batch kernel always.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
  * "chunk_blocks": blocks per kernel launch of a long batch (default and maximum 2^20; a test knob). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 

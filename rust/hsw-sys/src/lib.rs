@@ -136,6 +136,21 @@ pub struct hsw_frame_desc {
     pub is_input_range_check: u32,
 }
 
+/// `hsw_witness_digests`: block streams + frames of n equally sized digests in one call.
+#[repr(C)]
+pub struct hsw_digests_args {
+    pub blocks: hsw_witness_args,
+    pub descs: *const hsw_frame_desc,
+    pub n_digests: usize,
+    pub d_blocks0: *const u8,
+    pub d_pre_states0: *const u32,
+    pub d_next_states0: *const u32,
+    pub d_gate0: *mut c_void,
+    pub d_lookup0: *mut c_void,
+    pub frame_pack: *const hsw_pack_plan,
+    pub host_next_states: *mut u32,
+}
+
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]
 pub struct hsw_digest_info {
@@ -264,6 +279,8 @@ extern "C" {
     pub fn hsw_engine_stream(e: *const hsw_engine, hip_stream: *mut *mut c_void, device: *mut c_int) -> c_int;
     pub fn hsw_engine_set_option(e: *mut hsw_engine, name: *const c_char, value: i64) -> c_int;
     pub fn hsw_last_launch(e: *const hsw_engine, out: *mut hsw_launch_info) -> c_int;
+    /// Block streams and frames of n equally sized digests in one call (one kernel launch up to 32 blocks).
+    pub fn hsw_witness_digests(e: *mut hsw_engine, args: *const hsw_digests_args) -> c_int;
 
     /// Replaces the block loop of reference src/lib.rs:180-238 over src/compression.rs:19-25.
     pub fn hsw_witness_blocks(e: *mut hsw_engine, d_blocks: *const u8, d_pre_states: *const u32,

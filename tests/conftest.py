@@ -27,6 +27,19 @@ def oracle():
     return O
 
 
+# Which expansion kernel the engines of engine_factory use for tiny batches: -1 = the product default (the
+# small-batch kernel of hsw_small.hpp up to 32 blocks), 0 = always hsw_expand_kernel.  The parity modules
+# run every test both ways (fixture kernel_choice) so that neither kernel loses its small-case coverage.
+_DEFAULT_SPLIT = [-1]
+
+
+@pytest.fixture(params=["default", "main-kernel"])
+def kernel_choice(request):
+    _DEFAULT_SPLIT[0] = -1 if request.param == "default" else 0
+    yield request.param
+    _DEFAULT_SPLIT[0] = -1
+
+
 @pytest.fixture(scope="session")
 def engine_factory(hsw):
     import torch
@@ -36,6 +49,7 @@ def engine_factory(hsw):
 
     def make(num_bits_lookup=8, num_advice_columns=2):
         e = hsw.WitnessEngine(0, num_bits_lookup, num_advice_columns)
+        e.set_option("split", _DEFAULT_SPLIT[0])
         engines.append(e)
         return e
 

@@ -14,12 +14,15 @@ def _inputs(n, seed):
             rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32))
 
 
-@pytest.fixture(scope="module")
-def eng_int(hsw):
+@pytest.fixture(scope="module", params=["default", "main-kernel"])
+def eng_int(hsw, request):
+    """Tiny batches go to the small-batch kernel by default (hsw_small.hpp); "main-kernel" pins the same
+    tests to hsw_expand_kernel so that neither loses its coverage."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     e = hsw.WitnessEngine(0, 8, 2, mode=hsw._native.HSW_MODE_HALO2_INTERNALS)
+    e.set_option("split", -1 if request.param == "default" else 0)
     yield e
     e.close()
 

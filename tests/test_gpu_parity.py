@@ -5,7 +5,7 @@ Integer / byte work: the bar is bit-exact equality of every cell.
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_choice")]
 
 
 def _rand_inputs(n, seed):

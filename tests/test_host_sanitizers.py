@@ -15,7 +15,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     kernels = [os.path.join(CSRC, f) for f in ("hsw_kernels.o", "hsw_frame.o", "hsw_verify.o", "hsw_expand_l1.o", "hsw_expand_l2.o",
-                                               "hsw_expand_l4.o", "hsw_expand_l8.o", "hsw_expand_l16.o", "hsw_expand_l8_rc.o", "hsw_expand_l16_rc.o")]
+                                               "hsw_expand_l4.o", "hsw_expand_l8.o", "hsw_expand_l16.o", "hsw_expand_l8_rc.o", "hsw_expand_l16_rc.o", "hsw_small_l2.o")]
     if not all(os.path.exists(k) for k in kernels):
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     exe = str(tmp_path / "host_sanity")

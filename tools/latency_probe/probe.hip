@@ -1,0 +1,85 @@
+// In-kernel timeline of small expansion launches (tuning aid; not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHSW_STAMPS -I../../halo2-dynamic-sha256_amd/csrc probe.hip -o probe
+// Every wave stamps the 100 MHz wall clock at: 0 entry, 1 chain done, 2 seeds pulled, 3 rounds phase done,
+// 4 exit.  Prints, per launch configuration, the kernel's event-timed duration and the distribution of the
+// stamps relative to the earliest entry.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "hsw_small.hpp"
+
+namespace hsw {
+template hipError_t launch_expand_L<2>(const ExpandParams &, int, hipStream_t);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ void empty_kernel(int *p) { if (p && threadIdx.x == 1000) *p = 1; }
+
+int main(int argc, char **argv) {
+    const size_t NB = argc > 1 ? atoi(argv[1]) : 16;
+    const size_t G = hsw::Lay<2, false>::GATE_CELLS, LC = hsw::Lay<2, false>::LIMB_CALLS;
+    uint8_t *d_blocks; uint32_t *d_pre, *d_next; void *d_gate, *d_cd, *d_cs; unsigned long long *d_st;
+    CK(hipMalloc(&d_blocks, NB * 64)); CK(hipMalloc(&d_pre, NB * 32)); CK(hipMalloc(&d_next, NB * 32));
+    CK(hipMalloc(&d_gate, NB * (G + 4000) * 32)); CK(hipMalloc(&d_cd, NB * LC * 32)); CK(hipMalloc(&d_cs, NB * LC * 32));
+    CK(hipMalloc(&d_st, NB * 64 * 16 * 8));
+    CK(hipMemset(d_blocks, 0x5a, NB * 64)); CK(hipMemset(d_pre, 0x33, NB * 32));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(hsw::g_hsw_stamps), &d_st, sizeof d_st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {   // launch floor: an empty kernel between two events
+        std::vector<float> ms;
+        for (int i = 0; i < 20; i++) {
+            CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(empty_kernel, dim3(512), dim3(64), 0, 0, nullptr); CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1)); float m; CK(hipEventElapsedTime(&m, e0, e1)); ms.push_back(m);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("empty kernel (512 waves) between two events: median %.1f us, min %.1f us\n", ms[10] * 1e3, ms[0] * 1e3);
+    }
+    struct Cfg { const char *name; unsigned parts; unsigned flags; int tile; };
+    const Cfg cfgs[] = {{"small-batch kernel (37 waves/block, one sub-unit program each)", 37, 0, -1},
+                        {"split (32 waves/block, one phase each)", 32, hsw::HSW_K_SPLIT, 32},
+                        {"16 waves/block", 16, 0, 64}, {"4 waves/block", 4, 0, 64}};
+    for (const Cfg &c : cfgs) {
+        hsw::ExpandParams p{};
+        p.blocks = d_blocks; p.pre_states = d_pre; p.gate = d_gate; p.chip_dense = d_cd; p.chip_spread = d_cs;
+        p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
+        p.flags = c.flags; p.parts = c.parts;
+        std::vector<float> ms;
+        for (int i = 0; i < 12; i++) {
+            CK(hipMemset(d_st, 0, NB * 64 * 16 * 8));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            if (c.tile < 0) CK(hsw::launch_small_L<2>(p, nullptr, 0));
+            else CK(hsw::launch_expand_L<2>(p, c.tile, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1)); float m; CK(hipEventElapsedTime(&m, e0, e1)); ms.push_back(m);
+        }
+        const size_t waves = NB * c.parts;
+        std::vector<unsigned long long> st(waves * 16);
+        CK(hipMemcpy(st.data(), d_st, waves * 16 * 8, hipMemcpyDeviceToHost));
+        std::sort(ms.begin(), ms.end());
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < waves; w++) t0 = std::min(t0, st[w * 16]);
+        printf("%s, %zu blocks: kernel (events) median %.1f us min %.1f us\n", c.name, NB, ms[6] * 1e3, ms[0] * 1e3);
+        const char *names[5] = {"entry", "chain done", "seeds pulled", "rounds done", "exit"};
+        for (int k = 0; k < 5; k++) {
+            std::vector<double> v;
+            for (size_t w = 0; w < waves; w++) v.push_back((double)(st[w * 16 + k] - t0) * 0.01);   // 100 MHz -> us
+            std::sort(v.begin(), v.end());
+            printf("   %-13s min %6.2f  median %6.2f  max %6.2f us\n", names[k], v.front(), v[v.size() / 2], v.back());
+        }
+        // per-wave durations of the split-mode programs of block 0
+        if ((c.flags & hsw::HSW_K_SPLIT) || c.tile < 0) {
+            printf("   block 0, per wave: chain / seeds / program (us)\n   ");
+            for (unsigned w = 0; w < c.parts; w++)
+                printf("[%u] %.1f/%.1f/%.1f  ", w, (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 2] - st[w * 16 + 1]) * 0.01,
+                       (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01);
+            printf("\n");
+        }
+    }
+    return 0;
+}
