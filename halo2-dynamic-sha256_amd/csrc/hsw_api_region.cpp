@@ -423,6 +423,7 @@ static int check_frame_args(hsw_engine *e, const hsw_frame_desc *descs, const ui
         return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
     if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
     *brk = hsw::FrameBreaks{};
+    for (uint32_t k = 0; k < HSW_MAX_BREAKS; k++) brk->cell[k] = ~0ull;      // unused entries: beyond every stream cell
     if (pack) {
         brk->n = pack->n_breaks;
         for (uint32_t k = 0; k < pack->n_breaks; k++) { brk->cell[k] = pack->break_cell[k]; brk->gap[k] = pack->break_gap[k]; }
@@ -479,7 +480,7 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
         return set_err(e, HSW_ERR_INVALID_ARG, "blocks.n_blocks / frame_every do not match the digests");
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
-    if (!hsw_small_eligible(e, b.n_blocks)) {
+    if (!hsw_small_eligible(e, b.n_blocks) || a->descs[0].n_blocks > 32) {      // (the frame waves stage <= 33 states in LDS)
         // two launches: the expansion, then the frames from the next states it left in HBM
         rc = hsw_witness_blocks_ex(e, &b);
         if (rc == HSW_OK)

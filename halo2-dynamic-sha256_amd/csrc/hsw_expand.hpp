@@ -274,8 +274,31 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
     constexpr int S = EM::STRIDE;
     const u32 lane = threadIdx.x;
     char *base = reinterpret_cast<char *>(em.out);
-    const bool packed = em.brk1 != 0xffffffffu;          // wave-uniform; false unless a pack plan is in force
     const u32 skew = EM::REALIGN ? em.skew : 0u;
+    // FlexGate column breaks inside this block (wave-uniform; none unless a pack plan is in force): a flush
+    // whose cells all lie on one side of them is only SHIFTED by the gaps it has passed and keeps the fast
+    // paths; only a flush that straddles a break places every piece on its own (`packed`).
+    u32 shift = 0;
+    bool packed = false;
+    const u32 lo_c = em.cell_base + (u32)fl * (u32)T - skew;                           // LDS column 0 of row 0
+    if (em.brk1 != 0xffffffffu) {
+        const u32 hi_c = lo_c + (em.nrows ? em.nrows - 1u : 0u) * em.unit_cells + (u32)T + 8u;   // past the last row's last piece
+        if (em.brk1 >= hi_c) shift = 0;
+        else if (em.brk1 <= lo_c && em.brk2 >= hi_c) shift = em.gap1;
+        else if (em.brk2 <= lo_c) shift = em.gap1 + em.gap2;
+        else packed = true;
+    }
+    // ... and inside a straddling flush every ROW is again either shifted as a whole or (at most two of them)
+    // straddles a break itself: returns the row's shift, `strad` = place the row piece by piece
+    auto row_shift = [&](u32 r, bool &strad) -> u32 {
+        const u32 row_lo = lo_c + r * em.unit_cells, row_hi = row_lo + (u32)T + 8u;
+        strad = false;
+        if (em.brk1 >= row_hi) return 0u;
+        if (em.brk1 <= row_lo && em.brk2 >= row_hi) return em.gap1;
+        if (em.brk2 <= row_lo) return em.gap1 + em.gap2;
+        strad = true;
+        return 0u;
+    };
     // A skewed unit shares its first line with the previous unit's tail, which is written at the END of
     // the phase: the first 4 - skew cells of every unit but the wave's first are held back in em.head and
     // appended to the previous row's tail in the last flush, so that the shared line is completed within
@@ -316,19 +339,21 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
         };
         // an unskewed partial flush without column breaks (every flush of the small-batch kernel's last
         // tile): rows x [0, ncells) with constant strides, no division per piece
-        const bool plain_partial = !FULL && !packed && skew == 0u;
+        const bool plain_partial = !FULL && skew == 0u;
         if (plain_partial) {
             const u32 row_bytes = em.unit_cells * (EM::COMPACT ? 8u : 32u);
             if constexpr (EM::COMPACT) {
-                u32 off = (em.cell_base + seg + lane) * 8u;
                 const u64 *src = em.tile + lane;
-                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes)
-                    for (u32 q = 0; lane + q < ncells; q += 64) store8(base, off + q * 8u, src[q]);
+                u32 cl0 = em.cell_base + seg + lane;
+                for (u32 r = 0; r < em.nrows; r++, src += S, cl0 += em.unit_cells)
+                    for (u32 q = 0; lane + q < ncells; q += 64)
+                        store8(base, (packed ? packed_cell(em, cl0 + q) : cl0 + q + shift) * 8u, src[q]);
             } else if constexpr (EM::MONT) {
-                u32 off = (em.cell_base + seg + lane) * 32u;
                 const u64 *src = em.tile + lane;
-                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes)
+                u32 cl0 = em.cell_base + seg + lane;
+                for (u32 r = 0; r < em.nrows; r++, src += S, cl0 += em.unit_cells)
                     for (u32 q = 0; lane + q < ncells; q += 64) {
+                        const u32 off = (packed ? packed_cell(em, cl0 + q) : cl0 + q + shift) * 32u - q * 32u;
                         const u64 v = src[q];
                         Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
                         if (any_neg) {
@@ -342,8 +367,12 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                 // stale cells of the same row -- read, never stored), then the stores
                 const u32 h = lane & 1u, p0 = lane >> 1;
                 const u64 *src = em.tile + p0;
-                u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
+                const u32 cell0 = em.cell_base + seg + p0;
+                u32 off = ((cell0 + shift) * 2u + h) * 16u;
                 for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+                    bool strad = false;
+                    u32 offr = off;
+                    if (packed) offr = ((cell0 + r * em.unit_cells + row_shift(r, strad)) * 2u + h) * 16u;
                     u64 vv[T / 32];
 #pragma unroll
                     for (int k = 0; k < T / 32; k++) vv[k] = src[32 * k];
@@ -357,7 +386,9 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                                 o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
                                       : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                         }
-                        if (p0 + 32u * (u32)k < ncells) store16(base, off + 1024u * (u32)k, o);
+                        u32 o_off = offr + 1024u * (u32)k;
+                        if (strad) o_off = (packed_cell(em, cell0 + r * em.unit_cells + 32u * (u32)k) * 2u + h) * 16u;
+                        if (p0 + 32u * (u32)k < ncells) store16(base, o_off, o);
                     }
                 }
             }
@@ -369,7 +400,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                 const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = lo0 + i - r * ncols;
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                if (packed) cl = packed_cell(em, cl);
+                cl = packed ? packed_cell(em, cl) : cl + shift;
                 store8(base, cl * 8u, em.tile[r * S + p]);
             }
         } else if constexpr (EM::MONT) {
@@ -386,20 +417,24 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                     if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
                 }
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                if (packed) cl = packed_cell(em, cl);
+                cl = packed ? packed_cell(em, cl) : cl + shift;
                 store16(base, cl * 32u, make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]));
                 store16(base, cl * 32u + 16u, make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]));
             }
-        } else if (FULL && !packed) {
-            // the common case: a full tile, no column break in this block.  Lane l owns the
-            // 16-byte piece (l & 1) of LDS column (l >> 1) + 32 k of every row; LDS and HBM
-            // addresses advance by constants.
+        } else if (FULL) {
+            // the common case: a full tile.  Lane l owns the 16-byte piece (l & 1) of LDS column
+            // (l >> 1) + 32 k of every row; LDS and HBM addresses advance by constants (a row next to a
+            // column break is re-based, one that straddles it placed piece by piece).
             const u32 h = lane & 1u, p0 = lane >> 1;
             const u64 *src = em.tile + p0;
-            u32 off = ((em.cell_base + seg + p0) * 2u + h) * 16u;
+            const u32 cell0 = em.cell_base + seg + p0;
+            u32 off = ((cell0 + shift) * 2u + h) * 16u;
             const u32 row_bytes = em.unit_cells * 32u;
             for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
                 const bool skip0 = first_skewed && p0 < (r == 0u ? lo0 : lo);
+                bool strad = false;
+                u32 offr = off;
+                if (packed) offr = ((cell0 + r * em.unit_cells + row_shift(r, strad)) * 2u + h) * 16u;
 #pragma unroll
                 for (int k = 0; k < T / 32; k++) {
                     const u64 v = src[32 * k];
@@ -410,12 +445,13 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                             o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
                                   : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                     }
-                    if (k != 0 || !skip0) store16(base, off + 1024u * (u32)k, o);
+                    u32 o_off = offr + 1024u * (u32)k;
+                    if (strad) o_off = (packed_cell(em, cell0 + r * em.unit_cells + 32u * (u32)k) * 2u + h) * 16u;
+                    if (k != 0 || !skip0) store16(base, o_off, o);
                 }
             }
         } else {
-            // (a FULL flush that lands here -- a column break in this block -- walks all T columns and
-            //  skips the empty / held-back ones of a skewed unit's first tile)
+            // (skewed partial flushes: every piece placed on its own)
             const u32 ppr = FULL ? 2u * (u32)T : 2u * ncols;        // 16-byte pieces per row
             const u32 total = FULL ? em.nrows * ppr : 2u * total_cells;
             for (u32 i = lane; i < total; i += 64) {
@@ -432,7 +468,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                               : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                 }
                 u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                if (packed) cl = packed_cell(em, cl);
+                cl = packed ? packed_cell(em, cl) : cl + shift;
                 store16(base, cl * 32u + h * 16u, o);
             }
         }

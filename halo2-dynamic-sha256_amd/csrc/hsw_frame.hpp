@@ -78,7 +78,7 @@ struct FrameDesc {
 
 // FlexGate column breaks applied to frame cells (absolute gate-stream indices), like
 // ExpandParams::break_cell / break_gap.
-struct FrameBreaks {
+struct FrameBreaks {      // entries past n: cell = UINT64_MAX, gap = 0 (the device code walks all 16)
     uint32_t n;
     uint64_t cell[16];
     uint64_t gap[16];

@@ -234,22 +234,30 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
                 framedev::frame_cells<REPR == 1>(d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_BYTES,
                                                  (slice - fr.state_waves) * 64u + lane, fr.byte_waves * 64u,
                                                  [](u32, u32) -> u32 { return 0u; });
+                HSW_STAMP(4);
                 return;
             }
             // candidate state n >= 1 = output of block n - 1 = pre-state of block n (the chain inputs); the
             // last block's output comes from the recurrence itself, computed here
-            const u32 *ps_last = fr.pre0 + 8 * (d.first_block + d.n_blocks - 1);
+            const u32 *ps0 = fr.pre0 + 8 * d.first_block, *ps_last = ps0 + 8 * (d.n_blocks - 1);
+            // (the pre-states may sit in pinned host memory: fetch them now, they arrive while the chain runs)
+            __shared__ u32 s_states[8 * 34];             // a small-batch launch has at most 32 blocks
+            const u32 nw = 8u * d.n_blocks;
+            u32 pre_w[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) pre_w[k] = lane + 64u * k < nw ? ps0[lane + 64u * k] : 0u;
             u32 lA, lE, lW;
             chain_latch<true>(reinterpret_cast<const u32 *>(fr.blocks0 + 64 * (d.first_block + d.n_blocks - 1)), ps_last,
                               64, 64 - (int)(lane & 3u), -1, lA, lE, lW);
-            __shared__ u32 s_last[8];
-            if (lane < 8) s_last[lane] = ps_last[lane] + (lane < 4 ? lA : lE);   // compression.rs:197-212
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) if (lane + 64u * k < nw) s_states[lane + 64u * k] = pre_w[k];
+            if (lane < 8) s_states[nw + lane] = ps_last[lane] + (lane < 4 ? lA : lE);   // compression.rs:197-212
             __syncthreads();
+            HSW_STAMP(1);
             framedev::frame_cells<REPR == 1>(
                 d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_STATES, slice * 64u + lane, fr.state_waves * 64u,
-                [&](u32 n, u32 i) -> u32 {
-                    return n == d.n_blocks ? s_last[i] : fr.pre0[8 * (d.first_block + n) + i];
-                });
+                [&](u32 n, u32 i) -> u32 { return s_states[8u * n + i]; });
+            HSW_STAMP(4);
             return;
         }
     }

@@ -81,5 +81,79 @@ int main(int argc, char **argv) {
             printf("\n");
         }
     }
+    {   // whole-digest launch: one digest of NB blocks (1,024-byte class), frames in the same grid, 9-column breaks
+        using LYR = hsw::Lay<2, true>;
+        const size_t GR = LYR::GATE_CELLS, PL = hsw::frame::prologue_cells(64 * NB, true), EL = hsw::frame::epilogue_cells(NB);
+        const size_t cells = PL + 1 + NB * GR + EL, rows = 131063;
+        void *d_gate2, *d_lk; unsigned long long *d_inv;
+        CK(hipMalloc(&d_gate2, (cells + 20 * rows) * 32)); CK(hipMalloc(&d_lk, (NB * LYR::LOOKUP_CELLS + 4 * 64 * NB + 128) * 32));
+        CK(hipMalloc(&d_inv, 64 * 32)); CK(hipMemset(d_inv, 1, 64 * 32));
+        hsw::ExpandParams p{};
+        p.blocks = d_blocks; p.pre_states = d_pre; p.gate = (char *)d_gate2 + (PL + 1) * 32; p.chip_dense = d_cd; p.chip_spread = d_cs;
+        p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
+        p.flags = hsw::HSW_K_INTERNALS; p.parts = 37;
+        p.lookup = (char *)d_lk + (3 + 2 * 64 * NB) * 32;
+        p.frame_every = NB; p.frame_cells = PL + EL; p.frame_lookups = 3 + 2 * 64 * NB + 64;
+        hsw::SmallFrames fr{};
+        fr.n_frames = 1; fr.state_waves = 4; fr.byte_waves = (unsigned)NB; fr.blocks0 = d_blocks; fr.pre0 = d_pre;
+        fr.gate0 = d_gate2; fr.lookup0 = d_lk; fr.inv_tbl = (const uint64_t *)d_inv;
+        for (int k = 0; k < 16; k++) fr.brk.cell[k] = ~0ull;
+        // column breaks every ~131,063 cells (relative to the block streams for the expansion, absolute for the frames)
+        unsigned nb = 0;
+        for (size_t c = rows - 50; c < cells && nb < 16; c += rows - 50, nb++) {
+            fr.brk.cell[nb] = c; fr.brk.gap[nb] = 50;
+            if (c > PL + 1) { p.break_cell[p.n_breaks] = c - (PL + 1); p.break_gap[p.n_breaks] = 50; p.n_breaks++; }
+        }
+        fr.brk.n = nb;
+        fr.d0.input_len = 56; fr.d0.first_block = 0; fr.d0.prologue_cell = 0; fr.d0.epilogue_cell = PL + 1 + NB * GR;
+        fr.d0.prologue_lookup = 0; fr.d0.epilogue_lookup = 3 + 2 * 64 * NB + NB * LYR::LOOKUP_CELLS; fr.d0.zero_cell = PL;
+        fr.d0.n_blocks = (unsigned)NB; fr.d0.num_round = 2; fr.d0.precomputed_round = 0; fr.d0.range_check_inputs = 1;
+        std::vector<float> ms;
+        const size_t waves = NB * 37 + 4 + NB;
+        for (int i = 0; i < 12; i++) {
+            CK(hipMemset(d_st, 0, (NB * 64) * 16 * 8));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            CK(hsw::launch_small_L<2>(p, &fr, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1)); float m; CK(hipEventElapsedTime(&m, e0, e1)); ms.push_back(m);
+        }
+        std::vector<unsigned long long> st(waves * 16);
+        CK(hipMemcpy(st.data(), d_st, waves * 16 * 8, hipMemcpyDeviceToHost));
+        std::sort(ms.begin(), ms.end());
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < waves; w++) t0 = std::min(t0, st[w * 16]);
+        printf("whole digest, %zu blocks + frames in one launch (%u breaks): kernel (events) median %.1f us min %.1f us\n", NB, nb, ms[6] * 1e3, ms[0] * 1e3);
+        double mx = 0;
+        for (size_t w = 0; w < NB * 37; w++) mx = std::max(mx, (st[w * 16 + 4] - t0) * 0.01);
+        printf("   block 0, per wave: chain / seeds / program (us)\n   ");
+        for (unsigned w = 0; w < 37; w++)
+            printf("[%u] %.1f/%.1f/%.1f  ", w, (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 2] - st[w * 16 + 1]) * 0.01,
+                   (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01);
+        printf("\n   block %zu, per wave: chain / seeds / program (us)\n   ", NB - 1);
+        for (unsigned w = 0; w < 37; w++) {
+            const size_t x = (NB - 1) * 37 + w;
+            printf("[%u] %.1f/%.1f/%.1f  ", w, (st[x * 16 + 1] - st[x * 16]) * 0.01, (st[x * 16 + 2] - st[x * 16 + 1]) * 0.01,
+                   (st[x * 16 + 4] - st[x * 16 + 2]) * 0.01);
+        }
+        {
+            std::vector<std::pair<double, size_t>> ex;
+            std::vector<double> en;
+            for (size_t w = 0; w < NB * 37; w++) { ex.push_back({(st[w * 16 + 4] - t0) * 0.01, w}); en.push_back((st[w * 16] - t0) * 0.01); }
+            std::sort(ex.begin(), ex.end()); std::sort(en.begin(), en.end());
+            printf("\n   entry: median %.2f  p90 %.2f  max %.2f us;  latest exits:", en[en.size() / 2], en[en.size() * 9 / 10], en.back());
+            for (size_t i = ex.size() - 6; i < ex.size(); i++) {
+                const size_t w = ex[i].second;
+                printf("  [blk %zu role %zu: entry %.1f chain %.1f prog %.1f exit %.1f]", w / 37, w % 37, (st[w * 16] - t0) * 0.01,
+                       (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01, ex[i].first);
+            }
+        }
+        printf("\n   expansion waves: last exit %.2f us\n   state waves (entry / chain+states done / exit): ", mx);
+        for (size_t w = NB * 37; w < NB * 37 + 4; w++)
+            printf("[%.1f %.1f %.1f] ", (st[w * 16] - t0) * 0.01, (st[w * 16 + 1] - t0) * 0.01, (st[w * 16 + 4] - t0) * 0.01);
+        printf("\n   byte waves (entry / exit): ");
+        for (size_t w = NB * 37 + 4; w < waves; w++) printf("[%.1f %.1f] ", (st[w * 16] - t0) * 0.01, (st[w * 16 + 4] - t0) * 0.01);
+        printf("\n");
+    }
     return 0;
 }
