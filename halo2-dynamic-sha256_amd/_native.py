@@ -77,6 +77,15 @@ class LaunchInfo(C.Structure):
                                                               "true" if self.internals else "false")
 
 
+class WideCell(C.Structure):
+    _fields_ = [("stream", C.c_uint64), ("index", C.c_uint64), ("value", C.c_uint64 * 4)]
+
+
+class RegionCompact(C.Structure):
+    _fields_ = [("gate", C.c_void_p), ("lookup", C.c_void_p), ("chip_dense", C.c_void_p), ("chip_spread", C.c_void_p),
+                ("wide", C.c_void_p), ("wide_cap", C.c_size_t), ("n_wide", C.c_size_t)]
+
+
 class DigestsArgs(C.Structure):
     """hsw_digests_args (descs: pointer to FrameDesc, declared below -> void pointer here)."""
     _fields_ = [("blocks", WitnessArgs), ("descs", C.c_void_p), ("n_digests", C.c_size_t), ("d_blocks0", C.c_void_p),
@@ -156,6 +165,7 @@ SYMBOLS = (
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
     "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
+    "hsw_gadget_download_region_compact", "hsw_region_widen",
 )
 
 
@@ -292,6 +302,14 @@ def lib():
         L.hsw_gadget_create_ex.restype = C.c_int
         L.hsw_gadget_create_ex.argtypes = [vp, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_uint32,
                                            C.POINTER(vp)]
+        L.hsw_last_launch.restype = C.c_int
+        L.hsw_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]
+        L.hsw_witness_digests.restype = C.c_int
+        L.hsw_witness_digests.argtypes = [vp, C.POINTER(DigestsArgs)]
+        L.hsw_gadget_download_region_compact.restype = C.c_int
+        L.hsw_gadget_download_region_compact.argtypes = [vp, C.POINTER(RegionCompact)]
+        L.hsw_region_widen.restype = C.c_int
+        L.hsw_region_widen.argtypes = [vp, C.c_size_t, C.c_uint64, vp, C.c_size_t, vp]
     _lib = L
     return L
 

@@ -340,6 +340,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
         // an unskewed partial flush without column breaks (every flush of the small-batch kernel's last
         // tile): rows x [0, ncells) with constant strides, no division per piece
         const bool plain_partial = !FULL && skew == 0u;
+        const u32 cell_sh = em.cell_base + seg + shift;     // (shift = 0 whenever packed)
         if (plain_partial) {
             const u32 row_bytes = em.unit_cells * (EM::COMPACT ? 8u : 32u);
             if constexpr (EM::COMPACT) {
@@ -399,8 +400,8 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
             for (u32 i = lane; i < total_cells; i += 64) {
                 const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = lo0 + i - r * ncols;
-                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                cl = packed ? packed_cell(em, cl) : cl + shift;
+                u32 cl = cell_sh + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
                 store8(base, cl * 8u, em.tile[r * S + p]);
             }
         } else if constexpr (EM::MONT) {
@@ -416,8 +417,8 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                 if (any_neg) {                        // compile-time false for most tiles
                     if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
                 }
-                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                cl = packed ? packed_cell(em, cl) : cl + shift;
+                u32 cl = cell_sh + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
                 store16(base, cl * 32u, make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]));
                 store16(base, cl * 32u + 16u, make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]));
             }
@@ -467,8 +468,8 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                         o = h ? make_uint4(HSW_P4, HSW_P5, HSW_P6, HSW_P7)
                               : make_uint4(HSW_P0 - vlo, HSW_P1, HSW_P2, HSW_P3);
                 }
-                u32 cl = em.cell_base + seg + r * em.unit_cells + p;
-                cl = packed ? packed_cell(em, cl) : cl + shift;
+                u32 cl = cell_sh + r * em.unit_cells + p;
+                if (packed) cl = packed_cell(em, cl);
                 store16(base, cl * 32u + h * 16u, o);
             }
         }

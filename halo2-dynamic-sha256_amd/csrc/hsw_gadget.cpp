@@ -211,6 +211,9 @@ Context::~Context() {
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
     (void)hipFree(d_init_states); (void)hipFree(d_offsets); (void)hipFree(d_lookup);
     if (hp_blocks) (void)hipHostFree(hp_blocks);
+    (void)hipFree(d_c_gate); (void)hipFree(d_c_lookup); (void)hipFree(d_c_dense); (void)hipFree(d_c_spread);
+    (void)hipFree(d_wide); (void)hipFree(d_wide_count);
+    if (hp_wide_count) (void)hipHostFree(hp_wide_count);
 }
 
 int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
@@ -805,6 +808,88 @@ int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) try {
     }
     if (he == hipSuccess) he = hipStreamSynchronize(stream);
     return he == hipSuccess ? HSW_OK : HSW_ERR_HIP;
+} HSW_NO_UNWIND
+
+int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst) try {
+    if (!g || !dst) return HSW_ERR_INVALID_ARG;
+    hsw::Context &c = *g->ctx;
+    if (c.repr_flags != HSW_REPR_CANONICAL) return HSW_ERR_UNSUPPORTED;      // packs canonical 32-byte cells
+    if (!dst->wide && dst->wide_cap) return HSW_ERR_INVALID_ARG;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    hsw_engine_stream(c.engine, reinterpret_cast<void **>(&stream), &device);
+    hsw::DeviceScopeG ds(device);
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
+    const uint32_t ncols = c.shape.num_advice_columns;
+    const size_t chip_cells = (size_t)ncols * (c.chip_col_stride ? c.chip_col_stride : 1);
+    const size_t gate_cells = c.whole ? (c.max_rows ? (size_t)(c.max_rows * (c.break_cell.size() + 1)) : (size_t)c.gate_capacity)
+                                      : c.capacity_blocks * (size_t)c.shape.gate_cells_per_block;
+    hipError_t he = hipSuccess;
+    if (!c.d_wide) {        // first use: the 8-byte staging of every stream, the side list and its counter
+        // wide cells: 4 ch negations per round (256 per block) + a few dozen per digest frame
+        c.wide_cap = c.capacity_blocks * 256 + 128 * (c.init_capacity + 1) + 4 * c.capacity_blocks + 64;
+        he = hipMalloc(&c.d_c_gate, (gate_cells ? gate_cells : 1) * 8);
+        if (he == hipSuccess && c.d_lookup) he = hipMalloc(&c.d_c_lookup, (size_t)(c.lookup_capacity ? c.lookup_capacity : 1) * 8);
+        if (he == hipSuccess) he = hipMalloc(&c.d_c_dense, chip_cells * 8);
+        if (he == hipSuccess) he = hipMalloc(&c.d_c_spread, chip_cells * 8);
+        if (he == hipSuccess) he = hipMalloc((void **)&c.d_wide_count, sizeof(uint32_t));
+        if (he == hipSuccess) he = hipHostMalloc((void **)&c.hp_wide_count, sizeof(uint32_t), hipHostMallocDefault);
+        if (he == hipSuccess) he = hipMalloc(&c.d_wide, c.wide_cap * 48);
+        if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+    }
+    he = hipMemsetAsync(c.d_wide_count, 0, sizeof(uint32_t), stream);
+    auto pack = [&](uint64_t *h, void *d8, const void *d32, uint64_t sid, size_t cell0, size_t cells) {
+        if (he != hipSuccess || !cells || !h) return;
+        he = hsw::launch_pack64(static_cast<const uint8_t *>(d32) + cell0 * 32, static_cast<uint8_t *>(d8) + cell0 * 8, cells, sid,
+                                cell0, c.d_wide, (uint32_t)c.wide_cap, c.d_wide_count, stream);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(h + cell0, static_cast<uint8_t *>(d8) + cell0 * 8, cells * 8, hipMemcpyDeviceToHost, stream);
+    };
+    if (c.whole && c.max_rows) {
+        // ONE pass over the image from (column 0, row 0) to the last assigned cell: the few unassigned rows at
+        // the end of every column are zero on the device and travel as zeros (a launch and a copy per column
+        // would cost more than the bytes they save)
+        uint64_t last_col = 0, last_row = 0;
+        if (c.gate_cursor) { c.position(c.gate_cursor - 1, &last_col, &last_row); last_row += 1; }
+        pack(dst->gate, c.d_c_gate, c.d_gate, HSW_STREAM_GATE, 0, c.gate_cursor ? (size_t)(last_col * c.max_rows + last_row) : 0);
+    } else {
+        pack(dst->gate, c.d_c_gate, c.d_gate, HSW_STREAM_GATE, 0,
+             c.whole ? (size_t)c.gate_cursor : c.blocks_done * (size_t)c.shape.gate_cells_per_block);
+    }
+    if (c.d_lookup) pack(dst->lookup, c.d_c_lookup, c.d_lookup, HSW_STREAM_LOOKUP, 0, (size_t)c.lookup_cursor);
+    const size_t rows = (size_t)((c.num_limb_sum + ncols - 1) / ncols);
+    if (rows == c.chip_col_stride) {         // every column full: one pass per family
+        pack(dst->chip_dense, c.d_c_dense, c.d_chip_dense, HSW_STREAM_CHIP_DENSE, 0, rows * ncols);
+        pack(dst->chip_spread, c.d_c_spread, c.d_chip_spread, HSW_STREAM_CHIP_SPREAD, 0, rows * ncols);
+    } else {
+        for (uint32_t k = 0; k < ncols; k++) {
+            pack(dst->chip_dense, c.d_c_dense, c.d_chip_dense, HSW_STREAM_CHIP_DENSE, k * c.chip_col_stride, rows);
+            pack(dst->chip_spread, c.d_c_spread, c.d_chip_spread, HSW_STREAM_CHIP_SPREAD, k * c.chip_col_stride, rows);
+        }
+    }
+    // the side list: the counter and as many entries as the caller has room for, in one pass of copies
+    const size_t take = dst->wide_cap < c.wide_cap ? dst->wide_cap : c.wide_cap;
+    if (he == hipSuccess) he = hipMemcpyAsync(c.hp_wide_count, c.d_wide_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess && take) he = hipMemcpyAsync(dst->wide, c.d_wide, take * 48, hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    if (he != hipSuccess) return HSW_ERR_HIP;
+    dst->n_wide = *c.hp_wide_count;
+    if (dst->n_wide > take) return HSW_ERR_TOO_LARGE;         // n_wide says how many entries the region has
+    return HSW_OK;
+} HSW_NO_UNWIND
+
+int hsw_region_widen(const uint64_t *compact, size_t n_cells, uint64_t stream_id, const hsw_wide_cell *wide, size_t n_wide,
+                     void *cells32) try {
+    if ((!compact || !cells32) && n_cells) return HSW_ERR_INVALID_ARG;
+    if (!wide && n_wide) return HSW_ERR_INVALID_ARG;
+    uint64_t *out = static_cast<uint64_t *>(cells32);
+    for (size_t i = 0; i < n_cells; i++) { out[4 * i] = compact[i]; out[4 * i + 1] = 0; out[4 * i + 2] = 0; out[4 * i + 3] = 0; }
+    for (size_t k = 0; k < n_wide; k++) {
+        if (wide[k].stream != stream_id) continue;
+        if (wide[k].index >= n_cells) return HSW_ERR_INVALID_ARG;
+        std::memcpy(out + 4 * wide[k].index, wide[k].value, 32);
+    }
+    return HSW_OK;
 } HSW_NO_UNWIND
 
 int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {

@@ -113,6 +113,10 @@ class Context {
     uint32_t *hp_pre = nullptr, *hp_next = nullptr;
     uint8_t *dp_blocks = nullptr;        // ... and the device addresses of the same memory
     uint32_t *dp_pre = nullptr, *dp_next = nullptr;
+    // compact delivery (hsw_gadget_download_region_compact): 8-byte staging of the streams, side list, its counter
+    void *d_c_gate = nullptr, *d_c_lookup = nullptr, *d_c_dense = nullptr, *d_c_spread = nullptr, *d_wide = nullptr;
+    uint32_t *d_wide_count = nullptr, *hp_wide_count = nullptr;
+    size_t wide_cap = 0;
     uint32_t repr_flags = HSW_REPR_CANONICAL;
     // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
     // digest, back to back) and d_lookup the lookup-advice stream next to it

@@ -56,6 +56,9 @@ hipError_t launch_chain(const uint8_t *blocks, size_t n_messages, size_t blocks_
 hipError_t launch_chain_var(const uint8_t *blocks, size_t n_messages, const uint32_t *offsets,
                             const uint32_t *init_states, uint32_t *pre_states, hipStream_t stream);
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
+// 32-byte canonical cells -> 8-byte cells + side list of the cells wider than 64 bits (6 u64 per entry)
+hipError_t launch_pack64(const void *src32, void *dst8, size_t n_cells, uint64_t stream_id, uint64_t index0,
+                         void *wide, uint32_t wide_cap, uint32_t *wide_count, hipStream_t stream);
 
 struct FrameDesc;   // hsw_frame.hpp
 struct FrameBreaks;

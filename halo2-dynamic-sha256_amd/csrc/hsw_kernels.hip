@@ -68,6 +68,38 @@ __global__ __launch_bounds__(256) void hsw_fill_kernel(uint4 *dst, size_t n16, u
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = v;
 }
 
+// Compact transport of a finished region (hsw.h hsw_gadget_download_region_compact): cell i of a 32-byte
+// canonical stream becomes its low 64 bits; the few cells that do not fit (field negations, -2^16, negative
+// differences, is_zero inverses) are appended -- stream id, cell index, all four limbs -- to a side list.
+__global__ __launch_bounds__(256) void hsw_pack64_kernel(const uint4 *src, u64 *dst, size_t n_cells, u64 stream_id,
+                                                         u64 index0, u64 *wide, u32 wide_cap, u32 *wide_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        const uint4 lo = src[2 * i], hi = src[2 * i + 1];
+        dst[i] = (u64)lo.x | ((u64)lo.y << 32);
+        if (lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) {
+            const u32 k = atomicAdd(wide_count, 1u);
+            if (k < wide_cap) {
+                u64 *w = wide + 6 * (size_t)k;
+                w[0] = stream_id; w[1] = index0 + i;
+                w[2] = (u64)lo.x | ((u64)lo.y << 32); w[3] = (u64)lo.z | ((u64)lo.w << 32);
+                w[4] = (u64)hi.x | ((u64)hi.y << 32); w[5] = (u64)hi.z | ((u64)hi.w << 32);
+            }
+        }
+    }
+}
+
+hipError_t launch_pack64(const void *src32, void *dst8, size_t n_cells, uint64_t stream_id, uint64_t index0,
+                         void *wide, uint32_t wide_cap, uint32_t *wide_count, hipStream_t stream) {
+    if (n_cells == 0) return hipSuccess;
+    const size_t want = (n_cells + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(hsw_pack64_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(src32),
+                       reinterpret_cast<u64 *>(dst8), n_cells, stream_id, index0, reinterpret_cast<u64 *>(wide), wide_cap,
+                       wide_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;

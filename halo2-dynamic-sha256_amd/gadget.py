@@ -145,6 +145,38 @@ class Sha256DynamicConfig:
             out["lookup"] = lookup[: int(v.lookup_cells)]
         return out
 
+    def download_region_compact(self, bufs=None):
+        """hsw_gadget_download_region_compact into pinned host arrays: 8-byte cells + the side list of the cells
+        wider than 64 bits.  Returns (bufs, n_wide); pass `bufs` back in to reuse the buffers.  widen() rebuilds
+        the 32-byte streams on the host (hsw_region_widen)."""
+        import numpy as np
+        v = self.view()
+        ncols = self.engine.ncols
+        img = self.whole_digest and int(v.max_rows)
+        n_gate = int(v.max_rows) * int(v.columns) if img else (
+            int(v.gate_cells) if self.whole_digest else int(v.blocks_done) * self.engine.G)
+        stride = int(v.chip_col_stride)
+        if bufs is None:
+            cap = 300 * max(int(v.capacity_blocks), 1) + 4096
+            bufs = dict(gate=self.engine.host_empty((max(n_gate, 1),)), dense=self.engine.host_empty((ncols * stride,)),
+                        spread=self.engine.host_empty((ncols * stride,)), wide=self.engine.host_empty((cap, 6)), cap=cap)
+            bufs["lookup"] = self.engine.host_empty((max(int(v.lookup_cells), 1),)) if self.whole_digest else None
+            if img:
+                bufs["gate"][:] = 0
+        dst = N.RegionCompact(bufs["gate"].ctypes.data, bufs["lookup"].ctypes.data if bufs["lookup"] is not None else None,
+                              bufs["dense"].ctypes.data, bufs["spread"].ctypes.data, bufs["wide"].ctypes.data, bufs["cap"], 0)
+        self._ok(self.lib.hsw_gadget_download_region_compact(self.h, C.byref(dst)))
+        return bufs, int(dst.n_wide)
+
+    def widen(self, compact, stream_id, wide, n_wide):
+        """hsw_region_widen: one stream's 32-byte canonical cells from its compact form + the side list."""
+        import numpy as np
+        compact = np.ascontiguousarray(compact, dtype=np.uint64).reshape(-1)
+        out = np.zeros((compact.size, 4), dtype=np.uint64)
+        self._ok(self.lib.hsw_region_widen(compact.ctypes.data, compact.size, stream_id, wide.ctypes.data, n_wide,
+                                           out.ctypes.data))
+        return out
+
     def verify(self):
         """hsw_gadget_verify: everything written so far against the constraint system, on the device."""
         rep = N.VerifyReport()

@@ -539,6 +539,34 @@ typedef struct hsw_region_host {
     void *gate, *lookup, *chip_dense, *chip_spread;
 } hsw_region_host;
 int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst);
+/* The same delivery in the compact transport form: canonical cells travel as their low 64 bits (a quarter
+ * of the bytes over PCIe) and the few cells of a region that do not fit -- the field negations of ch, -2^16,
+ * the negative differences and is_zero inverses of the frames -- as a side list of (stream, cell index, four
+ * limbs).  Layouts as in hsw_gadget_download_region with 8-byte cells (a column image travels in one piece:
+ * the unassigned rows at the end of a column arrive as the zeros they are on the device); `wide` receives up to wide_cap entries
+ * (in no particular order), n_wide how many the region has (HSW_ERR_TOO_LARGE if more than wide_cap: a block
+ * has at most 256, a frame a few dozen).  hsw_region_widen rebuilds one stream's 32-byte cells on the host.
+ * Canonical representation only (Montgomery cells are all full width). */
+#define HSW_STREAM_GATE        0u
+#define HSW_STREAM_LOOKUP      1u
+#define HSW_STREAM_CHIP_DENSE  2u
+#define HSW_STREAM_CHIP_SPREAD 3u
+typedef struct hsw_wide_cell {
+    uint64_t stream;               /* HSW_STREAM_* */
+    uint64_t index;                /* cell index in that stream's buffer */
+    uint64_t value[4];             /* canonical little-endian limbs */
+} hsw_wide_cell;
+typedef struct hsw_region_compact {
+    uint64_t *gate, *lookup, *chip_dense, *chip_spread;     /* host buffers, 8 bytes per cell; NULL = skipped */
+    hsw_wide_cell *wide;
+    size_t wide_cap;
+    size_t n_wide;                                          /* out */
+} hsw_region_compact;
+int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst);
+/* Host helper: cells32[i] = compact[i] widened to 32 bytes, then the side-list entries of `stream_id`
+ * (indices relative to the same buffer) copied over them. */
+int hsw_region_widen(const uint64_t *compact, size_t n_cells, uint64_t stream_id, const hsw_wide_cell *wide,
+                     size_t n_wide, void *cells32);
 /* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
  * (cur_hash_idx, num_limb_sum, the gate / lookup stream cursors, the zero cell) takes the value it
  * would have then.  All of them follow from max_variable_byte_sizes alone -- never from the

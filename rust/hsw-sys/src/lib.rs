@@ -151,6 +151,31 @@ pub struct hsw_digests_args {
     pub host_next_states: *mut u32,
 }
 
+pub const HSW_STREAM_GATE: u64 = 0;
+pub const HSW_STREAM_LOOKUP: u64 = 1;
+pub const HSW_STREAM_CHIP_DENSE: u64 = 2;
+pub const HSW_STREAM_CHIP_SPREAD: u64 = 3;
+
+/// One cell wider than 64 bits in the compact delivery of a region.
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct hsw_wide_cell {
+    pub stream: u64,
+    pub index: u64,
+    pub value: [u64; 4],
+}
+
+#[repr(C)]
+pub struct hsw_region_compact {
+    pub gate: *mut u64,
+    pub lookup: *mut u64,
+    pub chip_dense: *mut u64,
+    pub chip_spread: *mut u64,
+    pub wide: *mut hsw_wide_cell,
+    pub wide_cap: usize,
+    pub n_wide: usize,
+}
+
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]
 pub struct hsw_digest_info {
@@ -281,6 +306,9 @@ extern "C" {
     pub fn hsw_last_launch(e: *const hsw_engine, out: *mut hsw_launch_info) -> c_int;
     /// Block streams and frames of n equally sized digests in one call (one kernel launch up to 32 blocks).
     pub fn hsw_witness_digests(e: *mut hsw_engine, args: *const hsw_digests_args) -> c_int;
+    pub fn hsw_gadget_download_region_compact(g: *mut hsw_gadget, dst: *mut hsw_region_compact) -> c_int;
+    pub fn hsw_region_widen(compact: *const u64, n_cells: usize, stream_id: u64, wide: *const hsw_wide_cell,
+                            n_wide: usize, cells32: *mut c_void) -> c_int;
 
     /// Replaces the block loop of reference src/lib.rs:180-238 over src/compression.rs:19-25.
     pub fn hsw_witness_blocks(e: *mut hsw_engine, d_blocks: *const u8, d_pre_states: *const u32,

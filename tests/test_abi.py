@@ -26,6 +26,15 @@ def test_header_symbols_all_exported(hsw):
     assert lib.hsw_abi_version() == 2
 
 
+def test_every_bound_function_has_a_signature(hsw):
+    """ctypes passes Python ints as 32-bit C ints unless argtypes says otherwise: a binding without a
+    signature truncates 64-bit pointers (a host-side crash waiting to happen)."""
+    lib = hsw._native.lib()
+    for name in hsw._native.SYMBOLS:
+        f = getattr(lib, name)
+        assert f.argtypes is not None or name == "hsw_abi_version", "no argtypes for %s" % name
+
+
 def test_library_is_in_tree_and_has_gfx950_code(hsw):
     path = hsw._native.LIB_PATH
     assert path.startswith(ROOT) and os.path.exists(path)

@@ -410,3 +410,84 @@ def test_whole_digest_other_spread_column_counts(hsw, oracle, ncols):
     assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]]) and np.array_equal(st["spread"], ref["spread"][:, : st["rows"]])
     for m, r in zip(msgs, res):
         assert r.output_bytes == hashlib.sha256(m).digest()
+
+
+@pytest.mark.parametrize("sizes", [[7680], [1024] * 7 + [512]], ids=["1x120blocks", "8digests"])
+@pytest.mark.parametrize("mont", [False, True], ids=["canonical", "montgomery"])
+def test_k20_region_of_120_blocks(hsw, oracle, eng_int, sizes, mont):
+    """BASELINE configs[4] substitute: the region of a k = 20 circuit -- max_rows = 2^20 - 9
+    (lib.rs:351-360), ~120 blocks at 9 advice columns, input range checks on (create_proof itself needs the
+    Rust prover: not runnable here).  One 120-block digest, and eight digests of two sizes in one context:
+    the linear stream + lookup + chip columns and the FlexGate column image, canonical and Montgomery,
+    against the oracle and a Python model of assign_region, and verified on the device."""
+    N = hsw._native
+    max_rows = (1 << 20) - 9
+    msgs = [bytes(((i * 7 + 3 * k) % 256) for i in range(s - 9 - 5 * k)) for k, s in enumerate(sizes)]
+    assert sum(sizes) // 64 == 120
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    conv = oracle.to_montgomery if mont else (lambda x: x)
+    img, (last_col, end_row) = _model_columns(ref["call_lens"], conv(ref["gate"]), max_rows)
+    for columns in (False, True):
+        cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+        if mont:
+            cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+        if columns:
+            assert cfg.set_columns(max_rows) == img.shape[0] == 8      # 8.4 M cells in 2^20-row columns (9 configured)
+        res = cfg.digest_batch(msgs)
+        assert [r.output_bytes for r in res] == [hashlib.sha256(m).digest() for m in msgs] == ref["digests"]
+        rep = cfg.verify()
+        assert rep["violations"] == 0 and rep["checks"] > 120 * 69348 // 4, rep
+        st = cfg.streams()
+        if columns:
+            bad = np.nonzero((st["gate"] != img).any(axis=2))
+            assert len(bad[0]) == 0, "first differing (column, row): %s" % [(int(c), int(r)) for c, r in zip(*bad)][:6]
+            assert cfg.cell_position(res[-1].end_cell - 1) == (last_col, end_row - 1)
+            host = cfg.download_region(pinned=True)
+            assert np.array_equal(host["gate"], img) and np.array_equal(host["lookup"], conv(ref["lookup"]))
+        else:
+            assert np.array_equal(st["gate"], conv(ref["gate"]))
+        assert np.array_equal(st["lookup"], conv(ref["lookup"]))
+        assert np.array_equal(st["dense"], conv(ref["dense"])[:, : st["rows"]])
+        assert np.array_equal(st["spread"], conv(ref["spread"])[:, : st["rows"]])
+        cfg.close()
+
+
+@pytest.mark.parametrize("columns", [False, True])
+def test_compact_delivery_of_a_whole_region(hsw, oracle, eng_int, columns):
+    """hsw_gadget_download_region_compact: the region crosses PCIe as 8-byte cells plus a side list of the cells
+    wider than 64 bits (ch negations, -2^16, negative differences, is_zero inverses); widened on the host
+    (hsw_region_widen) it is the 32-byte image bit for bit.  TestCircuit shape and a three-digest context with a
+    target round below the maximum (negative n - target, inverses)."""
+    N = hsw._native
+    for sizes, msgs in (([128, 128], [b"abc", b""]), ([256, 64, 192], [b"q" * 70, b"", bytes(range(100))])):
+        cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+        if columns:
+            cfg.set_columns(100000)
+        cfg.digest_batch(msgs)
+        full = cfg.download_region(pinned=False)
+        bufs, n_wide = cfg.download_region_compact()
+        bufs, n_wide2 = cfg.download_region_compact(bufs)            # buffers reusable, list rebuilt from scratch
+        assert n_wide == n_wide2
+        nblk = sum(sizes) // 64
+        assert 0 < n_wide <= 256 * nblk + 64 * len(sizes)
+        wide = bufs["wide"]
+        v = cfg.view()
+        g = cfg.widen(bufs["gate"], N.HSW_STREAM_GATE if hasattr(N, "HSW_STREAM_GATE") else 0, wide, n_wide)
+        assert np.array_equal(g.reshape(full["gate"].shape), full["gate"])
+        lk = cfg.widen(bufs["lookup"][: int(v.lookup_cells)], 1, wide, n_wide)
+        assert np.array_equal(lk, full["lookup"])
+        stride = int(v.chip_col_stride)
+        d = cfg.widen(bufs["dense"], 2, wide, n_wide).reshape(2, stride, 4)[:, : full["rows"]]
+        s = cfg.widen(bufs["spread"], 3, wide, n_wide).reshape(2, stride, 4)[:, : full["rows"]]
+        assert np.array_equal(d, full["dense"]) and np.array_equal(s, full["spread"])
+        # the side list holds exactly the cells with a non-zero upper limb
+        flat = full["gate"].reshape(-1, 4)
+        n_expected = int(flat[:, 1:].any(axis=1).sum())
+        assert n_wide == n_expected
+        # too small a side list is reported, with the size needed
+        small = N.RegionCompact(bufs["gate"].ctypes.data, None, None, None, bufs["wide"].ctypes.data, 3, 0)
+        assert cfg.lib.hsw_gadget_download_region_compact(cfg.h, C.byref(small)) == N.HSW_ERR_TOO_LARGE and small.n_wide == n_wide
+        cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+        with pytest.raises(hsw.HswError):
+            cfg.download_region_compact(bufs)
+        cfg.close()
