@@ -372,6 +372,29 @@ def extra_config1(hsw, eng, dev, local_rank, alg_bytes):
     res["device_resident_chain_plus_expand"] = {"ms_per_message": dt * 1e3, "blocks_per_s": 16 / dt,
                                                 "GBps": 16 * alg_bytes / dt / 1e9,
                                                 "frac_of_peak": 16 * alg_bytes / dt / 1e9 / HBM_PEAK_GBS}
+    try:   # HSW_CHAINED: ONE launch, every wave derives its block's pre-state itself (no chain pre-pass)
+        iv = torch.from_numpy(IV.view(np.int32).copy()).to(dev)
+        CH = hsw._native.HSW_CHAINED
+        for _ in range(3):
+            eng.witness_blocks(b16, iv, out=o16, flags=CH)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.witness_blocks(b16, iv, out=o16, flags=CH)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t1) / reps
+        kc = []
+        for _ in range(8):
+            eng.witness_blocks(b16, iv, out=o16, flags=CH)
+            kc.append(eng.last_kernel_ms())
+        last = o16["next_states"][15].cpu().numpy().view(np.uint32)
+        assert b"".join(int(x).to_bytes(4, "big") for x in last) == hashlib.sha256(m).digest()
+        res["device_resident_chained_single_launch"] = {
+            "ms_per_message": dtc * 1e3, "blocks_per_s": 16 / dtc, "kernel_ms": float(np.median(kc)),
+            "GBps": 16 * alg_bytes / dtc / 1e9, "frac_of_peak": 16 * alg_bytes / dtc / 1e9 / HBM_PEAK_GBS,
+            "note": "HSW_CHAINED: d_pre_states = the message's initial state; block b's waves walk b compressions to their pre-state"}
+    except Exception as ex:
+        res["device_resident_chained_single_launch"] = {"error": repr(ex)}
     try:   # the same two launches captured into one HIP graph and replayed
         gs = torch.cuda.Stream()
         eng_g = hsw.WitnessEngine(local_rank, 8, 2, stream=gs)

@@ -26,6 +26,7 @@ HSW_SKIP_GATE = 2
 HSW_SKIP_CHIP = 4
 HSW_HOST_REGISTER = 8
 HSW_REPR_COMPACT64 = 16
+HSW_CHAINED = 32
 HSW_MODE_DEFAULT = 0
 HSW_MODE_HALO2_INTERNALS = 1
 HSW_MAX_BREAKS = 16

@@ -346,8 +346,10 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
     uint32_t *d_next_states = args->d_next_states;
     const uint32_t flags = args->flags;
     if (n_blocks == 0) return HSW_OK;
-    if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP))
+    if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP | HSW_CHAINED))
         return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
+    if ((flags & HSW_CHAINED) && (!hsw_small_eligible(e, n_blocks) || n_blocks > e->chunk_blocks || frames))
+        return set_err(e, HSW_ERR_UNSUPPORTED, "HSW_CHAINED: small-batch launches only (<= 32 blocks, 8-bit table); run hsw_sha256_chain first");
     if ((flags & HSW_REPR_MASK) == HSW_REPR_MASK)
         return set_err(e, HSW_ERR_INVALID_ARG, "HSW_REPR_MONTGOMERY and HSW_REPR_COMPACT64 are exclusive");
     const size_t cb = hsw_cell_bytes(flags);
@@ -419,7 +421,8 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
         p.flags = (want_gate ? 0u : hsw::HSW_K_SKIP_GATE) | (want_chip ? 0u : hsw::HSW_K_SKIP_CHIP) |
                   ((flags & HSW_REPR_MONTGOMERY) ? hsw::HSW_K_MONTGOMERY : 0u) |
                   ((flags & HSW_REPR_COMPACT64) ? hsw::HSW_K_COMPACT : 0u) |
-                  (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u);
+                  (e->mode == HSW_MODE_HALO2_INTERNALS ? hsw::HSW_K_INTERNALS : 0u) |
+                  ((flags & HSW_CHAINED) ? hsw::HSW_K_CHAINED : 0u);
         p.frame_every = args->frame_every;
         p.frame_cells = args->frame_cells;
         p.frame_lookups = args->frame_lookups;
@@ -725,6 +728,7 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
     if (!e) return HSW_ERR_INVALID_ARG;
     if (n_blocks == 0) return HSW_OK;
     if (!blocks || !pre_states) return set_err(e, HSW_ERR_INVALID_ARG, "null input pointer");
+    if (flags & HSW_CHAINED) return set_err(e, HSW_ERR_UNSUPPORTED, "HSW_CHAINED is for device-resident launches");
     if (!gate) flags |= HSW_SKIP_GATE;
     if (!chip_dense || !chip_spread) flags |= HSW_SKIP_CHIP;
     DeviceScope ds(e->device);

@@ -119,7 +119,7 @@ static int ensure_structure(hsw_engine *e) {
     void *d = nullptr;
     hipError_t he = hipMalloc(&d, bytes);
     if (he == hipSuccess) he = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipMalloc((void **)&e->d_report, sizeof(hsw::VerifyReport));
+    if (he == hipSuccess && !e->d_report) he = hipMalloc((void **)&e->d_report, sizeof(hsw::VerifyReport));   // (hsw_verify_frames may have made it)
     if (he != hipSuccess) { if (d) (void)hipFree(d); return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "structure upload", he); }
     e->d_structure = d;
     const uint8_t *b = static_cast<const uint8_t *>(d);
@@ -153,6 +153,15 @@ int hsw_verify_blocks(hsw_engine *e, const hsw_witness_args *args, hsw_verify_re
         return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
     if ((args->d_chip_dense == nullptr) != (args->d_chip_spread == nullptr)) return set_err(e, HSW_ERR_INVALID_ARG, "both chip families or none");
     if (args->d_lookup && e->mode != HSW_MODE_HALO2_INTERNALS) return set_err(e, HSW_ERR_INVALID_ARG, "d_lookup needs HSW_MODE_HALO2_INTERNALS");
+    // the kernel reads cells as 16-byte pieces at (N % ncols) * chip_col_stride + row: the same alignment and
+    // stride rules as for hsw_witness_blocks_ex, or a bad argument would become a device fault
+    if (((uintptr_t)args->d_gate & 15u) || ((uintptr_t)args->d_chip_dense & 15u) || ((uintptr_t)args->d_chip_spread & 15u) ||
+        ((uintptr_t)args->d_lookup & 15u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "stream buffers must be 16-byte aligned");
+    if (((uintptr_t)args->d_blocks & 3u) || ((uintptr_t)args->d_pre_states & 3u) || ((uintptr_t)args->d_next_states & 3u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "inputs must be 4-byte aligned");
+    if (args->d_chip_dense && args->chip_col_stride < hsw_chip_rows(&e->shape, args->spread_cursor0, args->n_blocks))
+        return set_err(e, HSW_ERR_INVALID_ARG, "chip_col_stride smaller than hsw_chip_rows()");
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
     const int rc = ensure_structure(e);
@@ -208,6 +217,9 @@ int hsw_verify_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, cons
         return set_err(e, HSW_ERR_INVALID_ARG, "digest frames need an engine created with HSW_MODE_HALO2_INTERNALS");
     if (flags & HSW_REPR_COMPACT64) return set_err(e, HSW_ERR_UNSUPPORTED, "hsw_verify_frames checks 32-byte cells (canonical or Montgomery)");
     if (pack && pack->n_breaks > HSW_MAX_BREAKS) return set_err(e, HSW_ERR_INVALID_ARG, "too many column breaks");
+    if (((uintptr_t)d_gate & 15u) || ((uintptr_t)d_lookup & 15u)) return set_err(e, HSW_ERR_INVALID_ARG, "gate / lookup buffer not 16-byte aligned");
+    if (((uintptr_t)d_blocks & 3u) || ((uintptr_t)d_pre_states & 3u) || ((uintptr_t)d_next_states & 3u))
+        return set_err(e, HSW_ERR_INVALID_ARG, "inputs must be 4-byte aligned");
     for (size_t i = 0; i < n; i++) {
         if (descs[i].n_blocks == 0 || descs[i].n_blocks != descs[0].n_blocks ||
             (descs[i].is_input_range_check != 0) != (descs[0].is_input_range_check != 0))

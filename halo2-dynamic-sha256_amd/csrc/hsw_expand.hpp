@@ -110,6 +110,14 @@ DEV u32 even_bits(u32 x) {
     return x;
 }
 
+// The SHA-256 functions on dense words, three-input boolean ops as one v_bitop3 each.
+DEV u32 sha_S1(u32 e) { return __builtin_amdgcn_bitop3_b32(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25), 0x96); }
+DEV u32 sha_S0(u32 a) { return __builtin_amdgcn_bitop3_b32(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22), 0x96); }
+DEV u32 sha_s0(u32 w) { return __builtin_amdgcn_bitop3_b32(rotr32(w, 7), rotr32(w, 18), w >> 3, 0x96); }
+DEV u32 sha_s1(u32 w) { return __builtin_amdgcn_bitop3_b32(rotr32(w, 17), rotr32(w, 19), w >> 10, 0x96); }
+DEV u32 sha_ch(u32 e, u32 f, u32 g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }    // e ? f : g
+DEV u32 sha_maj(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
+
 // ---------------------------------------------------------- Montgomery form
 // HSW_REPR_MONTGOMERY: a cell holds x * 2^256 mod p, halo2curves' in-memory Fr.
 // For x = lo + hi*2^32 < 2^64:  x*R mod p = lo*R + hi*R32 (mod p) with the

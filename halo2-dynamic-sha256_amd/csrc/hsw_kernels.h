@@ -16,6 +16,7 @@ enum : uint32_t {
     HSW_K_COMPACT = 8u,      // HSW_REPR_COMPACT64: 8-byte cells
     HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
     HSW_K_SPLIT = 32u,       // 32 waves per block, each running one phase program (tiny batches: latency)
+    HSW_K_CHAINED = 64u,     // small-batch kernel: the blocks are ONE message, pre_states holds its initial state only
 };
 enum { HSW_K_MAX_BREAKS = 16 };
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)

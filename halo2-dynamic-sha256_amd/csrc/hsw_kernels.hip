@@ -22,18 +22,10 @@ DEV void chain_message(const uint8_t *blocks, size_t first_blk, size_t nblk, con
         u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
         for (int t = 0; t < 64; t++) {
-            if (t >= 16) {
-                const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
-                const u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-                const u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-                w[t & 15] = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
-            }
-            const u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-            const u32 chv = (e & f) ^ (~e & g);
-            const u32 t1 = h + S1 + chv + K256[t] + w[t & 15];
-            const u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-            const u32 mj = (a & b) ^ (a & c) ^ (b & c);
-            const u32 t2 = S0 + mj;
+            if (t >= 16)
+                w[t & 15] = w[t & 15] + sha_s0(w[(t - 15) & 15]) + w[(t - 7) & 15] + sha_s1(w[(t - 2) & 15]);
+            const u32 t1 = h + K256[t] + w[t & 15] + sha_S1(e) + sha_ch(e, f, g);
+            const u32 t2 = sha_S0(a) + sha_maj(a, b, c);
             h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
         st[0] += a; st[1] += b; st[2] += c; st[3] += d;

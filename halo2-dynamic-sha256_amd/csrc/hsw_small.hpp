@@ -62,13 +62,6 @@ enum : u32 {
 };
 static_assert(SMALL_ROLES == HSW_SMALL_WAVES_PER_BLOCK, "hsw_kernels.h");
 
-DEV u32 sha_S1(u32 e) { return __builtin_amdgcn_bitop3_b32(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25), 0x96); }
-DEV u32 sha_S0(u32 a) { return __builtin_amdgcn_bitop3_b32(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22), 0x96); }
-DEV u32 sha_s0(u32 w) { return __builtin_amdgcn_bitop3_b32(rotr32(w, 7), rotr32(w, 18), w >> 3, 0x96); }
-DEV u32 sha_s1(u32 w) { return __builtin_amdgcn_bitop3_b32(rotr32(w, 17), rotr32(w, 19), w >> 10, 0x96); }
-DEV u32 sha_ch(u32 e, u32 f, u32 g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }    // e ? f : g
-DEV u32 sha_maj(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
-
 // The plain SHA-256 recurrence of one block, wave-uniform, through registers.  Index convention: A_t / E_t
 // are the a / e words at the START of round t (A_0 = a, A_-1 = b, A_-2 = c, A_-3 = d of the pre-state; round
 // t works on a..d = A_t..A_t-3, e..h = E_t..E_t-3), W_t the schedule word of round t.  Runs rounds
@@ -265,7 +258,49 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
     const size_t blk = blockIdx.x / SMALL_ROLES;
     const u32 role = blockIdx.x % SMALL_ROLES;
     const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
-    const u32 *ps = p.pre_states + 8 * blk;
+    u32 ps[8];                                   // this block's pre-state (wave-uniform)
+    if (p.flags & HSW_K_CHAINED) {
+        // ONE message: pre_states holds its initial state only; block b's pre-state is b compressions away
+        // (the roles that never look at the state skip the walk)
+#pragma unroll
+        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[i];
+        const bool needs_state = role < SMALL_ROUND_ROLES || role == SMALL_ROLE_FEED || role == SMALL_ROLE_STATE;
+        if (needs_state && blk != 0) {
+            // the message schedules of the blocks before this one do not depend on the state: lane l expands
+            // block l's (all at once), K + W goes through LDS (the tile is not in use yet; rows 65 words apart:
+            // no bank conflicts), and only the 64-round recurrence of each block remains serial
+            u32 *s_kw = reinterpret_cast<u32 *>(s_tile);
+            static_assert(sizeof(s_tile) >= 32 * 65 * 4, "K + W of 31 blocks must fit the tile");
+            if (lane < (u32)blk) {
+                const u32 *bl = reinterpret_cast<const u32 *>(p.blocks + 64 * (size_t)lane);
+                u32 w[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(bl[j]);
+#pragma unroll
+                for (int t = 0; t < 64; t++) {
+                    if (t >= 16)
+                        w[t & 15] = w[t & 15] + sha_s0(w[(t + 1) & 15]) + w[(t + 9) & 15] + sha_s1(w[(t + 14) & 15]);
+                    s_kw[lane * 65u + (u32)t] = w[t & 15] + K256[t];
+                }
+            }
+            __syncthreads();
+            for (u32 b = 0; b < (u32)blk; b++) {
+                u32 a = ps[0], bb = ps[1], c = ps[2], d = ps[3], e = ps[4], f = ps[5], g = ps[6], h = ps[7];
+                const u32 *kw = s_kw + b * 65u;
+#pragma unroll 16
+                for (int t = 0; t < 64; t++) {
+                    const u32 t1 = h + kw[t] + sha_S1(e) + sha_ch(e, f, g);
+                    const u32 t2 = sha_S0(a) + sha_maj(a, bb, c);
+                    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                }
+                ps[0] += a; ps[1] += bb; ps[2] += c; ps[3] += d; ps[4] += e; ps[5] += f; ps[6] += g; ps[7] += h;
+            }
+            __syncthreads();                       // the tile takes the memory over
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[8 * blk + i];
+    }
 
     EM em;
     em.lk16 = s_lk16;
@@ -394,7 +429,10 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
         u32 lA, lE, lW;
         chain_latch<true>(bw, ps, 64, 64 - (int)(lane & 3u), -1, lA, lE, lW);       // lanes 0..3: A_64..A_61 / E_64..E_61
         HSW_STAMP(1);
-        const u32 fx = lane < 4 ? lA : lE, fy = ps[lane & 7u];
+        u32 fy = ps[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) fy = (lane & 7u) == (u32)i ? ps[i] : fy;
+        const u32 fx = lane < 4 ? lA : lE;
         if (lane < 8) {
             if (p.next_states != nullptr) p.next_states[8 * blk + lane] = fy + fx;
             if (p.next_states_host != nullptr) p.next_states_host[8 * blk + lane] = fy + fx;
@@ -433,8 +471,10 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
         HSW_STAMP(3);
     } else {
         // ---- 6 x state_to_spread_u32 of a,b,c,e,f,g: compression.rs:109-115 (d and h are never spread) --
-        const u32 u = lane < 6 ? lane : 5u;
-        const u32 word = ps[u < 3 ? u : u + 1];
+        const u32 u = lane < 6 ? lane : 5u, wi = u < 3 ? u : u + 1;      // a, b, c, e, f, g
+        u32 word = ps[0];
+#pragma unroll
+        for (int i = 1; i < 7; i++) word = wi == (u32)i ? ps[i] : word;
         HSW_STAMP(1); HSW_STAMP(2);
         if (phase_begin(em, 0, 1, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
             auto c1 = state_to_spread<L>(CurStart{}, em, word);

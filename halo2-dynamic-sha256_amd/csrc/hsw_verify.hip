@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         }
         if (act && !ok && j4 == 0) fail(VERIFY_GATE_ROW, c);
         // ---- this lane's cell
+        if constexpr (MONT)            // a Montgomery cell is an encoding m < p: m + p reduces to the same value and would pass everything below
+            if (act && geq_p(raw)) fail(VERIFY_RANGE, cell);
         if (act) {
             if (k == 1) { if (!same(x, small((u64)rf))) fail(VERIFY_CONSTANT, cell); }
             else if (k == 2) {
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
             const u32 lo = (u32)v.l[0], hi = (u32)(v.l[0] >> 32);
             const u32 plo = swap32(lo), phi = swap32(hi);                     // the partner's low limb
             bool ok = tied && narrow(v);
+            if constexpr (MONT) ok = ok && !geq_p(rv);                          // canonical encoding only
             if (half) ok = ok && phi == 0 && (u64)spread16(plo) == v.l[0];    // (dense, spread) is a row of the table
             else ok = ok && v.l[0] < (1ull << p.num_bits_lookup);
             const u32 both = (ok ? 1u : 0u) & swap32(ok ? 1u : 0u);
@@ -280,8 +283,11 @@ __global__ __launch_bounds__(256) void hsw_verify_kernel(VerifyParams p) {
         for (u32 j = tid; j < p.lookup_cells; j += nt) {
             bool known;
             const Cell src = cell_of(p.lookup_src[j], known);
-            const Cell v = load_value<MONT>(lk, p.lookup_cell0 + blk * (u64)p.lookup_cells + dg * p.frame_lookups + j);
-            if (!(narrow(v) && v.l[0] < 65536 && (!known || same(v, src)))) fail(VERIFY_LOOKUP, j);
+            const Cell rv = load_cell(lk, p.lookup_cell0 + blk * (u64)p.lookup_cells + dg * p.frame_lookups + j);
+            Cell v = rv;
+            bool enc = true;
+            if constexpr (MONT) { v = from_mont(rv); enc = !geq_p(rv); }
+            if (!(enc && narrow(v) && v.l[0] < 65536 && (!known || same(v, src)))) fail(VERIFY_LOOKUP, j);
         }
     }
     // 7. next-state words

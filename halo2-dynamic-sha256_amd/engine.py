@@ -97,7 +97,7 @@ class WitnessEngine:
         assert blocks.is_cuda and pre_states.is_cuda and blocks.is_contiguous() and pre_states.is_contiguous()
         assert blocks.dtype == t.uint8 and pre_states.dtype == t.int32
         n = blocks.numel() // 64
-        assert pre_states.numel() == 8 * n
+        assert pre_states.numel() == (8 if flags & N.HSW_CHAINED else 8 * n)
         if out is None:
             out = self.alloc_outputs(n, cursor0, flags)
         gate, dense, spread, nxt = out["gate"], out["dense"], out["spread"], out["next_states"]

@@ -79,6 +79,12 @@ extern "C" {
                                       copies are cut at that boundary; the <= 2 edge fragments (< 4 KiB
                                       each) and buffers below 64 KiB take ordinary pageable copies. */
 
+#define HSW_CHAINED            32u  /* hsw_witness_blocks(_ex): the n_blocks blocks are ONE message (lib.rs:180-238) and
+                                      d_pre_states holds its initial state only (8 words); every wave derives its
+                                      block's pre-state itself, so no chain pre-pass (hsw_sha256_chain) and no second
+                                      launch is needed.  Small-batch launches only (<= 32 blocks at the 8-bit table),
+                                      HSW_ERR_UNSUPPORTED otherwise.  d_next_states receives every block's output. */
+
 #define HSW_CELL_BYTES         32u
 
 typedef struct hsw_engine hsw_engine;

@@ -21,6 +21,8 @@ pub const HSW_SKIP_GATE: u32 = 2;
 pub const HSW_SKIP_CHIP: u32 = 4;
 pub const HSW_HOST_REGISTER: u32 = 8;
 pub const HSW_REPR_COMPACT64: u32 = 16;
+/// The blocks are ONE message; `d_pre_states` holds its initial state only (small-batch launches).
+pub const HSW_CHAINED: u32 = 32;
 pub const HSW_MODE_DEFAULT: u32 = 0;
 pub const HSW_MODE_HALO2_INTERNALS: u32 = 1;
 pub const HSW_MAX_BREAKS: usize = 16;

@@ -90,7 +90,7 @@ class Fuzzer:
         flags = int(rng.choice([0, N.HSW_REPR_MONTGOMERY, N.HSW_REPR_COMPACT64]))
         tile, parts = [(0, 0), (32, 1), (32, 4), (32, 32), (64, 2), (64, 4), (64, 16), (128, 4), (128, 8), (128, 32),
                        (0, 1), (0, 8)][int(rng.integers(0, 12))]
-        split = int(rng.choice([-1, -1, 0, 1]))
+        split = int(rng.choice([-1, -1, 0, 1, 2]))
         shift = int(rng.choice([0, 0, 1, 2, 3]))
         pack = rng.random() < 0.4
         chunk = int(rng.choice([1 << 20, 1 << 20, 1, 3, 5]))      # blocks per launch: reach the multi-launch loop

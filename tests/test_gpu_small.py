@@ -158,3 +158,44 @@ def test_one_launch_whole_digest_equals_two_launches(hsw, oracle, mont):
             eng.close()
         for k in ("gate", "lookup", "dense", "spread"):
             assert np.array_equal(got[0][k], got[1][k]), (sizes, k)
+
+
+@pytest.mark.parametrize("nblk,flags_name", [(1, "canonical"), (16, "canonical"), (16, "montgomery"), (32, "canonical")])
+def test_chained_single_launch(hsw, oracle, nblk, flags_name):
+    """HSW_CHAINED: the blocks are ONE message and d_pre_states holds its initial state only -- every wave
+    walks the message to its own block, no chain pre-pass, no second launch (BASELINE configs[1]: one
+    16-block message).  Streams, chip columns and every block's next state against the oracle's digest() run."""
+    import hashlib
+    import torch
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 2)
+    m = bytes(((i * 131 + 7) % 256) for i in range(64 * nblk - 9))
+    ref = oracle.Oracle(8, 2, check=True).digest(m, 64 * nblk, want_streams=True)
+    assert ref["digest"] == hashlib.sha256(m).digest()
+    flags = N.HSW_CHAINED | (N.HSW_REPR_MONTGOMERY if flags_name == "montgomery" else 0)
+    conv = oracle.to_montgomery if flags_name == "montgomery" else (lambda x: x)
+    tb = torch.from_numpy(ref["blocks"].copy()).cuda()
+    init = torch.from_numpy(oracle.INIT_STATE.view(np.int32).copy()).cuda()
+    out = eng.witness_blocks(tb, init, flags=flags)
+    eng.synchronize()
+    assert eng.last_launch()["split"] == 2
+    assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), conv(ref["gate"]))
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), conv(ref["dense"]))
+    assert np.array_equal(out["spread"].cpu().numpy().view(np.uint64), conv(ref["spread"]))
+    assert np.array_equal(out["next_states"].cpu().numpy().view(np.uint32), ref["next_states"])
+    # a custom initial state (precomputed prefix, lib.rs:153-160)
+    init2 = np.arange(8, dtype=np.uint32) * np.uint32(0x01234567)
+    st = init2.copy()
+    nxt = []
+    for j in range(min(nblk, 3)):
+        st = oracle.plain_compress(st, ref["blocks"][j])
+        nxt.append(st.copy())
+    out2 = eng.witness_blocks(tb[:3] if nblk >= 3 else tb, torch.from_numpy(init2.view(np.int32).copy()).cuda(), flags=N.HSW_CHAINED)
+    eng.synchronize()
+    assert np.array_equal(out2["next_states"].cpu().numpy().view(np.uint32)[: len(nxt)], np.stack(nxt))
+    # not a small-batch launch: refused, with a pointer to the pre-pass
+    big = torch.zeros((40, 64), dtype=torch.uint8, device="cuda")
+    with pytest.raises(hsw.HswError) as ei:
+        eng.witness_blocks(big, init, flags=N.HSW_CHAINED)
+    assert ei.value.status == N.HSW_ERR_UNSUPPORTED
+    eng.close()

@@ -278,3 +278,55 @@ def test_verify_montgomery_streams(engine_factory, hsw, eng_int):
     rep2 = cfg.verify()
     assert rep2["violations"] == 0 and rep2["checks"] > 4 * 80000
     cfg.close()
+
+
+def test_verify_rejects_non_canonical_montgomery_encodings_and_bad_arguments(engine_factory, hsw):
+    """A Montgomery cell is an encoding m < p.  m + p reduces to the same value, so a verifier that only
+    reduced on load would accept it: the stored limbs themselves must be < p.  And the argument checks of
+    hsw_witness_blocks_ex hold for the verifier too (a short stride / misaligned pointer must be an error
+    code, not a device fault)."""
+    import ctypes as C
+    import torch
+    N = hsw._native
+    P = [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029]
+    eng = engine_factory(8, 2)
+    blocks, pre = _inputs(3, 1234)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    out = eng.witness_blocks(tb, tp, flags=N.HSW_REPR_MONTGOMERY)
+    eng.synchronize()
+    a = N.WitnessArgs()
+    a.d_blocks, a.d_pre_states, a.n_blocks, a.spread_cursor0 = tb.data_ptr(), tp.data_ptr(), 3, 0
+    a.d_gate, a.d_chip_dense, a.d_chip_spread = out["gate"].data_ptr(), out["dense"].data_ptr(), out["spread"].data_ptr()
+    a.chip_col_stride, a.d_next_states, a.flags = out["dense"].shape[1], out["next_states"].data_ptr(), N.HSW_REPR_MONTGOMERY
+    rep = N.VerifyReport()
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations == 0
+
+    def add_p(t, idx):          # m -> m + p on the four little-endian limbs of cell idx (m + p < 2^255: no overflow)
+        limbs = [int(x) & 0xFFFFFFFFFFFFFFFF for x in t[idx].cpu().numpy().view(np.uint64)]
+        carry, res = 0, []
+        for l, pl in zip(limbs, P):
+            s = l + pl + carry
+            res.append(s & 0xFFFFFFFFFFFFFFFF)
+            carry = s >> 64
+        assert carry == 0
+        t[idx] = torch.from_numpy(np.array(res, dtype=np.uint64).view(np.int64)).to(t.device)
+        return limbs
+
+    cell = 2 * eng.G + 40000
+    saved = add_p(out["gate"], cell)
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0
+    assert rep.violations >= 1 and rep.first_block == 2 and rep.first_cell == 40000
+    out["gate"][cell] = torch.from_numpy(np.array(saved, dtype=np.uint64).view(np.int64)).cuda()
+    saved = add_p(out["dense"][1], 17)                     # a chip cell
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations >= 1
+    out["dense"][1][17] = torch.from_numpy(np.array(saved, dtype=np.uint64).view(np.int64)).cuda()
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == 0 and rep.violations == 0
+    # arguments
+    a.chip_col_stride = out["dense"].shape[1] - 1
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
+    a.chip_col_stride = out["dense"].shape[1]
+    a.d_gate = out["gate"].data_ptr() + 8
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
+    a.d_gate = out["gate"].data_ptr()
+    a.d_chip_spread = out["spread"].data_ptr() + 4
+    assert eng.lib.hsw_verify_blocks(eng.h, C.byref(a), C.byref(rep)) == N.HSW_ERR_INVALID_ARG
