@@ -87,6 +87,12 @@ class RegionCompact(C.Structure):
                 ("wide", C.c_void_p), ("wide_cap", C.c_size_t), ("n_wide", C.c_size_t)]
 
 
+class ResultCells(C.Structure):
+    _fields_ = [("input_len_cell", C.c_uint64), ("input_bytes_cell0", C.c_uint64), ("n_input_bytes", C.c_uint64),
+                ("output_byte_cells", C.c_uint64 * 32), ("input_len_pos", C.c_uint64 * 2),
+                ("input_bytes_pos0", C.c_uint64 * 2), ("output_byte_pos", (C.c_uint64 * 2) * 32)]
+
+
 class DigestsArgs(C.Structure):
     """hsw_digests_args (descs: pointer to FrameDesc, declared below -> void pointer here)."""
     _fields_ = [("blocks", WitnessArgs), ("descs", C.c_void_p), ("n_digests", C.c_size_t), ("d_blocks0", C.c_void_p),
@@ -166,7 +172,7 @@ SYMBOLS = (
     "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
     "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
-    "hsw_gadget_download_region_compact", "hsw_region_widen",
+    "hsw_gadget_download_region_compact", "hsw_region_widen", "hsw_gadget_result_cells",
 )
 
 
@@ -309,6 +315,8 @@ def lib():
         L.hsw_witness_digests.argtypes = [vp, C.POINTER(DigestsArgs)]
         L.hsw_gadget_download_region_compact.restype = C.c_int
         L.hsw_gadget_download_region_compact.argtypes = [vp, C.POINTER(RegionCompact)]
+        L.hsw_gadget_result_cells.restype = C.c_int
+        L.hsw_gadget_result_cells.argtypes = [vp, C.c_size_t, C.POINTER(ResultCells)]
         L.hsw_region_widen.restype = C.c_int
         L.hsw_region_widen.argtypes = [vp, C.c_size_t, C.c_uint64, vp, C.c_size_t, vp]
     _lib = L

@@ -12,6 +12,7 @@
 #endif
 
 #include "hsw_nounwind.hpp"
+#include "hsw_frame.hpp"
 #include "hsw_kernels.h"
 
 // library-internal entry points of hsw_api.cpp (hsw_engine.hpp)
@@ -745,6 +746,26 @@ int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t 
         if (cap < b.size()) return HSW_ERR_INVALID_ARG;
         if (!b.empty()) std::memcpy(out, b.data(), b.size());
     }
+    return HSW_OK;
+} HSW_NO_UNWIND
+
+int hsw_gadget_result_cells(const hsw_gadget *g, size_t hash_idx, hsw_result_cells *out) try {
+    if (!g || !out || hash_idx >= g->results.size()) return HSW_ERR_INVALID_ARG;
+    if (!g->ctx->whole) return HSW_ERR_INVALID_ARG;                  // block-stream contexts hold no frame cells
+    const hsw::AssignedHashResult &r = g->results[hash_idx];
+    std::memset(out, 0, sizeof *out);
+    out->input_len_cell = r.prologue_cell + hsw::frame::P_LEN;
+    out->input_bytes_cell0 = r.prologue_cell + hsw::frame::P_BYTES;
+    out->n_input_bytes = (uint64_t)r.n_blocks * 64;
+    g->ctx->position(out->input_len_cell, &out->input_len_pos[0], &out->input_len_pos[1]);
+    g->ctx->position(out->input_bytes_cell0, &out->input_bytes_pos0[0], &out->input_bytes_pos0[1]);
+    for (uint32_t w = 0; w < 8; w++)
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint64_t cell = r.epilogue_cell + (uint64_t)hsw::frame::E_STATE * (r.n_blocks + 1) +
+                                  (uint64_t)hsw::frame::E_WORD * w + 5u * i;
+            out->output_byte_cells[4 * w + i] = cell;
+            g->ctx->position(cell, &out->output_byte_pos[4 * w + i][0], &out->output_byte_pos[4 * w + i][1]);
+        }
     return HSW_OK;
 } HSW_NO_UNWIND
 

@@ -596,6 +596,21 @@ int hsw_gadget_digest_batch(hsw_gadget *g, size_t n, const uint8_t *const *input
                             const size_t *input_lens, const size_t *precomputed_input_lens,
                             hsw_hash_result *results);
 int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view);
+/* Where the cells of digest #hash_idx's AssignedHashResult (lib.rs:31-36, 342-346) sit -- what a shim
+ * needs to hand back to the circuit (the reference's TestCircuit constrains output_bytes to its instance
+ * column, lib.rs:480-482).  HSW_GADGET_WHOLE_DIGEST contexts only.  Cells are gate-stream indices;
+ * positions (column, row) of the same cells in the FlexGate image (identity column 0 without set_columns). */
+typedef struct hsw_result_cells {
+    uint64_t input_len_cell;            /* load_witness(input_byte_size), lib.rs:124-125 */
+    uint64_t input_bytes_cell0;         /* assigned_input_bytes[i] = cell input_bytes_cell0 + i (lib.rs:170-173) */
+    uint64_t n_input_bytes;             /* max_variable_byte_size */
+    uint64_t output_byte_cells[32];     /* the load_witness cells of the digest bytes (lib.rs:317-324) */
+    uint64_t input_len_pos[2];          /* (column, row) */
+    uint64_t input_bytes_pos0[2];       /* of input byte 0; byte i follows at i rows below unless a column break
+                                           lies in between: hsw_gadget_cell_position(input_bytes_cell0 + i) */
+    uint64_t output_byte_pos[32][2];
+} hsw_result_cells;
+int hsw_gadget_result_cells(const hsw_gadget *g, size_t hash_idx, hsw_result_cells *out);
 /* AssignedHashResult.input_bytes of digest #hash_idx (the padded variable part). */
 int hsw_gadget_input_bytes(hsw_gadget *g, size_t hash_idx, uint8_t *out, size_t cap, size_t *len);
 /* HSW_REPR_CANONICAL (default) or HSW_REPR_MONTGOMERY for subsequent digests. */

@@ -167,6 +167,19 @@ pub struct hsw_wide_cell {
     pub value: [u64; 4],
 }
 
+/// `hsw_gadget_result_cells`: where the cells of one digest's `AssignedHashResult` sit.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct hsw_result_cells {
+    pub input_len_cell: u64,
+    pub input_bytes_cell0: u64,
+    pub n_input_bytes: u64,
+    pub output_byte_cells: [u64; 32],
+    pub input_len_pos: [u64; 2],
+    pub input_bytes_pos0: [u64; 2],
+    pub output_byte_pos: [[u64; 2]; 32],
+}
+
 #[repr(C)]
 pub struct hsw_region_compact {
     pub gate: *mut u64,
@@ -308,6 +321,7 @@ extern "C" {
     pub fn hsw_last_launch(e: *const hsw_engine, out: *mut hsw_launch_info) -> c_int;
     /// Block streams and frames of n equally sized digests in one call (one kernel launch up to 32 blocks).
     pub fn hsw_witness_digests(e: *mut hsw_engine, args: *const hsw_digests_args) -> c_int;
+    pub fn hsw_gadget_result_cells(g: *const hsw_gadget, hash_idx: usize, out: *mut hsw_result_cells) -> c_int;
     pub fn hsw_gadget_download_region_compact(g: *mut hsw_gadget, dst: *mut hsw_region_compact) -> c_int;
     pub fn hsw_region_widen(compact: *const u64, n_cells: usize, stream_id: u64, wide: *const hsw_wide_cell,
                             n_wide: usize, cells32: *mut c_void) -> c_int;

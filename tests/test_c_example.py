@@ -54,3 +54,24 @@ def test_whole_region_example_runs_the_bench_circuit(tmp_path):
     assert "advice columns: 9 x 131063 rows; gate cells 1116315, lookup cells 53059" in r.stdout
     assert hashlib.sha256(bytes([1] * 56)).hexdigest() in r.stdout and r.stdout.strip().endswith("ok")
     assert " constraints, 0 violations" in r.stdout
+
+
+RESULT = os.path.join(ROOT, "examples", "assigned_hash_result.c")
+
+
+def test_assigned_hash_result_example_links(tmp_path):
+    _build(tmp_path, RESULT)
+
+
+@pytest.mark.gpu
+def test_assigned_hash_result_cells_through_the_c_abi(tmp_path):
+    """What the Rust shim's digest() must return -- AssignedHashResult { input_len, input_bytes, output_bytes }
+    (lib.rs:31-36) -- resolved to (column, row) of the advice image for the TestCircuit (3 columns) and the
+    bench circuit (9 columns), and read back there, from plain C."""
+    import hashlib
+    exe = _build(tmp_path, RESULT)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert hashlib.sha256(b"abc").hexdigest() in r.stdout and hashlib.sha256(b"").hexdigest() in r.stdout
+    assert hashlib.sha256(bytes([1] * 56)).hexdigest() in r.stdout and r.stdout.strip().endswith("ok")
+    assert "TestCircuit digest 0: input_len at (0, 0), input_bytes from (0, 46)" in r.stdout
