@@ -3,7 +3,8 @@
 usage: profile_extract.py stats <db> <out.csv>
        profile_extract.py stats_by_grid <db> <out.csv> [min grid]   (one line per kernel AND grid size: separates
                                                                      the 4,096-block launches from the small ones)
-       profile_extract.py traffic <write_db> <fetch_db> <out.json> <kernel substring> <algorithmic bytes per launch>"""
+       profile_extract.py traffic <write_db> <fetch_db> <out.json> <kernel substring> <algorithmic bytes per launch> [commit]
+       profile_extract.py sq <out.json> <db> [<db> ...]        (every counter of the pmc passes, averaged per kernel and grid size)"""
 import csv, json, sqlite3, sys
 
 
@@ -40,11 +41,28 @@ def counter(db, name, kernel):
     return dict(n=len(vals), mean=sum(vals) / len(vals), min=min(vals), max=max(vals)), rows[0][5], rows[0][3], rows[0][4], big
 
 
-def traffic(wdb, rdb, out, kernel, alg):
+def sq(out, dbs):
+    res = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        rows = cur.execute("select kernel_name, grid_size, counter_name, dispatch_id, sum(value) from counters_collection "
+                           "group by kernel_name, grid_size, counter_name, dispatch_id").fetchall()
+        acc = {}
+        for name, grid, ctr, disp, val in rows:
+            acc.setdefault(("%s grid=%d" % (name.split("(")[0], grid), ctr), []).append(val)
+        for (k, ctr), vals in acc.items():
+            d = res.setdefault(k, {})
+            d[ctr] = sum(vals) / len(vals)
+            d["launches"] = max(d.get("launches", 0), len(vals))
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+
+
+def traffic(wdb, rdb, out, kernel, alg, commit=None):
     w, name, lds, vgpr, grid = counter(wdb, "WRITE_SIZE", kernel)
     r, _, _, _, _ = counter(rdb, "FETCH_SIZE", kernel)
     wb, rb = w["mean"] * 1024, r["mean"] * 1024 * 2
     json.dump({
+        "commit": commit, "kernel": name.split("(")[0],
         "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra (one pass per counter)",
         "note": "MI355X_MICROARCH.md HBM section: WRITE_SIZE is exact for 16-B/lane streaming stores; FETCH_SIZE reads 1/2 of wide coalesced reads on gfx950 -> doubled. Units are KiB.",
         "kernel_name_seen": name, "lds_block_size": lds, "vgpr": vgpr, "grid": grid,
@@ -59,5 +77,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "stats_by_grid":
         stats_by_grid(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3:])
     else:
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]))
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), sys.argv[7] if len(sys.argv) > 7 else None)
