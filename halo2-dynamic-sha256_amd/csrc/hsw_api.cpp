@@ -214,6 +214,8 @@ void hsw_engine_destroy(hsw_engine *e) {
     if (!e) return;
     {
         DeviceScope ds(e->device);
+        (void)hipStreamSynchronize(e->stream);      // launches of this engine may still read the buffers freed below
+        if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
         free_pipeline(e);
         for (auto &fs : e->frame_slot) {
             if (fs.h) (void)hipHostFree(fs.h);

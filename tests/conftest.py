@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# glibc writes its fatal messages (heap corruption, double free) to the controlling terminal unless told
+# otherwise: a GPU-box run has no use for that -- keep them in the captured stderr.
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
