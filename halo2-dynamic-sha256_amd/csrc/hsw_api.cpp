@@ -623,45 +623,17 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         e->slot_rows = ch_rows;
     }
     const size_t rows_total = (size_t)hsw_chip_rows(&e->shape, cursor0, n_blocks);
-    // HSW_HOST_REGISTER: pin the caller's output buffers in place so that the copies write them directly.
-    // hipHostRegister works on whole pages, and the runtime takes any copy that STARTS in a registered page
-    // for a copy to pinned memory -- all of it, also the part past the registered range (a GPU memory fault,
-    // found by the fuzzer with two small chip arrays that shared a heap page).  So only the page INTERIOR of
-    // a buffer is registered -- [lo rounded up, hi rounded down): pages the buffer owns entirely, whatever
-    // allocator it came from -- and every D2H copy is split at the registration boundary (d2h below): no byte
-    // outside the caller's buffer is ever pinned, and no copy starts on one side of the boundary and ends
-    // on the other.  The <= 2 edge fragments (< 4 KiB each) take the pageable path.
-    struct Reg {
-        uintptr_t lo = 0, hi = 0;      // registered range, empty if lo == hi
-        void open(const void *ptr, size_t bytes) {
-            const uintptr_t PAGE = 4096;
-            const uintptr_t a = ((uintptr_t)ptr + PAGE - 1) & ~(PAGE - 1), b = ((uintptr_t)ptr + bytes) & ~(PAGE - 1);
-            if (bytes < 16 * PAGE || b <= a) return;          // not worth a registration
-            if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) { lo = a; hi = b; }
-            else (void)hipGetLastError();                     // e.g. already pinned by the caller: copy as it is
-        }
-        void close() { if (hi > lo) (void)hipHostUnregister((void *)lo); lo = hi = 0; }
-    } reg_gate, reg_cd, reg_cs;
-    if (pin) {
-        const size_t gate_bytes = want_gate ? n_blocks * G * cb : 0;
-        const size_t span = want_chip ? ((ncols - 1) * chip_col_stride + rows_total) * cb : 0;
-        if (gate_bytes) reg_gate.open(gate, gate_bytes);
-        if (span) { reg_cd.open(chip_dense, span); reg_cs.open(chip_spread, span); }
-    }
-    // D2H copy of [dst, dst + bytes), cut where it crosses the edge of the registered range
-    auto d2h = [&](const Reg &rg, void *dst, const void *src, size_t bytes, hipStream_t st) -> hipError_t {
-        uintptr_t d = (uintptr_t)dst;
-        const uintptr_t end = d + bytes;
-        const uint8_t *sp = static_cast<const uint8_t *>(src);
-        const uintptr_t cuts[2] = {rg.lo, rg.hi};
-        for (int k = 0; k < 2 && rg.hi > rg.lo; k++)
-            if (cuts[k] > d && cuts[k] < end) {
-                const size_t n = cuts[k] - d;
-                hipError_t r = hipMemcpyAsync((void *)d, sp, n, hipMemcpyDeviceToHost, st);
-                if (r != hipSuccess) return r;
-                d += n; sp += n;
-            }
-        return end > d ? hipMemcpyAsync((void *)d, sp, end - d, hipMemcpyDeviceToHost, st) : hipSuccess;
+    // HSW_HOST_REGISTER is accepted and ignored (`pin`): the library does not pin memory it does not own.
+    // Rounds 1 and 2 both tried hipHostRegister on the caller's buffers -- whole pages first, then only the page
+    // interior with every copy cut at the registration boundary -- and both ended in "Memory access fault by
+    // GPU ... on address <host heap>" under the randomised differential run (profiles/r01_fuzz_parity.json,
+    // profiles/r02_fuzz_parity.json): a user-pointer registration inside an allocator's heap does not survive
+    // the allocator trimming and re-growing that heap between calls.  Pageable destinations take the runtime's
+    // own staged copies; callers that want the PCIe rate allocate with hsw_host_alloc.
+    (void)pin;
+    (void)rows_total;
+    auto d2h = [&](void *dst, const void *src, size_t bytes, hipStream_t st) -> hipError_t {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
     };
     uint8_t *d_blocks = nullptr; uint32_t *d_pre = nullptr, *d_next = nullptr;
     do {
@@ -683,7 +655,7 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
             if (rc != HSW_OK) break;
             if ((he = hipEventRecord(s.kernel_done, e->stream)) != hipSuccess) { fail("record kernel_done"); break; }
             if ((he = hipStreamWaitEvent(e->copy_stream, s.kernel_done, 0)) != hipSuccess) { fail("wait kernel_done"); break; }
-            if (want_gate && (he = d2h(reg_gate, static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
+            if (want_gate && (he = d2h(static_cast<uint8_t *>(gate) + done * G * cb, s.gate,
                                        nb * G * cb, e->copy_stream)) != hipSuccess) { fail("D2H gate"); break; }
             if (want_chip) {
                 // only the last chunk can end inside a row: the cells of that row past the call's last limb
@@ -693,10 +665,10 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
                     const size_t dst = (c * chip_col_stride + row_off) * cb, src = c * e->slot_rows * cb;
                     const size_t own = rows - ((tail != 0 && c >= tail) ? 1 : 0);
                     if (own == 0) continue;
-                    he = d2h(reg_cd, static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
+                    he = d2h(static_cast<uint8_t *>(chip_dense) + dst, static_cast<uint8_t *>(s.cd) + src,
                              own * cb, e->copy_stream);
                     if (he == hipSuccess)
-                        he = d2h(reg_cs, static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
+                        he = d2h(static_cast<uint8_t *>(chip_spread) + dst, static_cast<uint8_t *>(s.cs) + src,
                                  own * cb, e->copy_stream);
                 }
                 if (he != hipSuccess) { fail("D2H chip columns"); break; }
@@ -709,7 +681,6 @@ static int pipelined_to_host(hsw_engine *e, const uint8_t *blocks, const uint32_
         if ((he = hipStreamSynchronize(e->copy_stream)) != hipSuccess) { fail("sync copy stream"); break; }
     } while (0);
     if (rc != HSW_OK) { (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->copy_stream); }
-    reg_gate.close(); reg_cd.close(); reg_cs.close();
     (void)hipFree(d_blocks); (void)hipFree(d_pre); (void)hipFree(d_next);
     return rc;
 }

@@ -72,13 +72,11 @@ extern "C" {
 #define HSW_SKIP_GATE          2u  /* do not write the gate stream (d_gate may be NULL) */
 #define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
 
-#define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only: pin the caller's output buffers
-                                      (hipHostRegister) for the duration of the call.  Registration is by
-                                      whole pages, so only the page INTERIOR of each buffer is pinned -- the
-                                      pages it owns entirely, whatever allocator it came from -- and the
-                                      copies are cut at that boundary; the <= 2 edge fragments (< 4 KiB
-                                      each) and buffers below 64 KiB take ordinary pageable copies. */
-
+#define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only.  Accepted and IGNORED since round 2: the library
+                                      never pins memory it does not own (hipHostRegister on a caller's heap buffers
+                                      ended in GPU memory faults twice: a user-pointer registration does not survive
+                                      the allocator trimming and re-growing its heap).  Pageable buffers take the
+                                      runtime's staged copies; for the PCIe rate allocate with hsw_host_alloc. */
 #define HSW_CHAINED            32u  /* hsw_witness_blocks(_ex): the n_blocks blocks are ONE message (lib.rs:180-238) and
                                       d_pre_states holds its initial state only (8 words); every wave derives its
                                       block's pre-state itself, so no chain pre-pass (hsw_sha256_chain) and no second

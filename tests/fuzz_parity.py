@@ -425,6 +425,27 @@ class Fuzzer:
         assert np.array_equal(a["lookup"][:lc], full["lookup"][:lc]) and np.array_equal(b["lookup"][lc:le], full["lookup"][lc:le])
         self.stats["seek_splits"] = self.stats.get("seek_splits", 0) + 1
 
+    # The case about to run is also written to a one-line trace file: a GPU fault ends the process without a
+    # Python exception, and the file then names the case that was on the device (HSW_FUZZ_TRACE overrides the path).
+    @property
+    def current(self):
+        return getattr(self, "_current", None)
+
+    @current.setter
+    def current(self, v):
+        self._current = v
+        if v is None:
+            return
+        if not hasattr(self, "_trace"):
+            path = os.environ.get("HSW_FUZZ_TRACE") or (os.path.join(ROOT, "gpurun_out", "fuzz_last_case.txt")
+                                                        if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+            self._trace = open(path, "w") if path else None
+        if self._trace:
+            self._trace.seek(0)
+            self._trace.truncate()
+            self._trace.write(repr(v) + "\n")
+            self._trace.flush()
+
     def run(self, seconds=None, iterations=None, log=None):
         t0 = time.time()
         it = 0
