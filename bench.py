@@ -713,6 +713,10 @@ def extra_multi_gpu(dist, sh, eng, blocks, pre, out, n, world, rank, value):
 
 # ------------------------------------------------------------------ one rank
 def run_rank(args):
+    # ONE JSON line on stdout: libraries that print there on their own (RCCL's version banner) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -730,6 +734,8 @@ def run_rank(args):
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))               # (set by the launcher; defaults for the 1-rank rehearsal)
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
@@ -899,7 +905,8 @@ def run_rank(args):
                                                 "achieved": mont["GBps"], "frac": mont["frac_of_peak"]}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(blocks_h, pre_h)
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
 
 
 def main():
