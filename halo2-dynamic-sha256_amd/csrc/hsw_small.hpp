@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
     em.carry_neg = 0;
     em.head = nullptr;
     em.d16 = s_d16;
+
     {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
         u64 first = (u64)blk * (u64)LY::GATE_CELLS;
         if constexpr (RC)
