@@ -391,6 +391,8 @@ static int stage_frame_descs(hsw_engine *e, const hsw_frame_desc *descs, size_t 
         while (cap < n) cap *= 2;
         he = hipHostMalloc((void **)&slot.h, cap * sizeof(hsw::FrameDesc), hipHostMallocMapped);
         if (he != hipSuccess) return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "hipHostMalloc", he);
+        he = hipHostGetDevicePointer((void **)&slot.d, slot.h, 0);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipHostGetDevicePointer", he);
         slot.cap = cap;
     }
     if (!slot.done) {
@@ -415,8 +417,7 @@ static int stage_frame_descs(hsw_engine *e, const hsw_frame_desc *descs, size_t 
     }
     int rc = ensure_inv_table(e, max_blocks + 1);
     if (rc != HSW_OK) return rc;
-    he = hipHostGetDevicePointer((void **)d_descs, slot.h, 0);
-    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipHostGetDevicePointer", he);
+    *d_descs = slot.d;
     *max_blocks_out = max_blocks;
     *slot_out = &slot;
     return HSW_OK;
@@ -524,8 +525,15 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
     fr.brk = brk;
     uint32_t *host_next = nullptr;
     if (a->host_next_states) {
-        hipError_t he = hipHostGetDevicePointer((void **)&host_next, a->host_next_states, 0);
-        if (he != hipSuccess) return set_err(e, HSW_ERR_INVALID_ARG, "host_next_states is not pinned, device-mapped host memory (hsw_host_alloc)", he);
+        // (a gadget hands in the same staging buffer at a moving offset: translate once per 64 KiB window)
+        const uintptr_t hp = (uintptr_t)a->host_next_states, lp = (uintptr_t)e->pin_host;
+        if (e->pin_host && hp >= lp && hp - lp < (1u << 16)) {
+            host_next = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(e->pin_dev) + (hp - lp));
+        } else {
+            hipError_t he = hipHostGetDevicePointer((void **)&host_next, a->host_next_states, 0);
+            if (he != hipSuccess) return set_err(e, HSW_ERR_INVALID_ARG, "host_next_states is not pinned, device-mapped host memory (hsw_host_alloc)", he);
+            e->pin_host = a->host_next_states; e->pin_dev = host_next;
+        }
     }
     rc = hsw_witness_blocks_impl(e, &b, &fr, host_next);
     if (rc != HSW_OK) return rc;

@@ -43,6 +43,7 @@ struct hsw_engine {
     // (no H2D copy, no stream sync unless four frame launches are already in flight)
     struct FrameSlot {
         hsw::FrameDesc *h = nullptr;
+        hsw::FrameDesc *d = nullptr;     // device address of h (pinned, device-mapped)
         size_t cap = 0;
         hipEvent_t done = nullptr;
         bool inflight = false;
@@ -57,6 +58,8 @@ struct hsw_engine {
     int verify_slices = 0;               // workgroups per block in hsw_verify_kernel; 0 = default
     hsw::VerifyReport *d_report = nullptr;
     hsw_launch_info last_launch{};       // hsw_last_launch
+    const void *pin_host = nullptr;      // last pinned host pointer translated for hsw_witness_digests ...
+    void *pin_dev = nullptr;             // ... and its device address
 };
 
 inline int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSuccess) {
@@ -76,13 +79,15 @@ bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks);
 int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
                             uint32_t *host_next_states);
 
-// Makes the engine's device current for the scope of one call.
+// Makes the engine's device current for the scope of one call (a no-op when it already is: the usual case,
+// and these scopes nest three deep on the latency-critical path of a small digest).
 struct DeviceScope {
     int prev = -1;
     bool ok = false;
     explicit DeviceScope(int dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) { ok = true; prev = -1; }
+        else ok = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceScope() {
         if (prev >= 0) (void)hipSetDevice(prev);

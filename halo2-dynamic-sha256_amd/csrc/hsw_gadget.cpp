@@ -122,7 +122,8 @@ struct DeviceScope {
     bool ok = false;
     explicit DeviceScope(int dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) { ok = true; prev = -1; }          // already current: nothing to set, nothing to restore
+        else ok = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
