@@ -373,6 +373,22 @@ static int ensure_inv_table(hsw_engine *e, size_t n) {
     return HSW_OK;
 }
 
+// One public descriptor checked (lib.rs:80-90) and turned into the device's form.
+static int convert_frame_desc(hsw_engine *e, const hsw_frame_desc &d, hsw::FrameDesc *out) {
+    if (d.n_blocks == 0) return set_err(e, HSW_ERR_UNSUPPORTED, "a digest frame needs max_variable_byte_size >= 64");
+    if ((uint64_t)d.num_round != (d.input_len + 9 + 63) / 64)
+        return set_err(e, HSW_ERR_INVALID_ARG, "num_round is not ceil((input_len + 9) / 64) (lib.rs:80-84)");
+    if (d.precomputed_round > d.num_round || d.num_round - d.precomputed_round > d.n_blocks)
+        return set_err(e, HSW_ERR_TOO_LARGE, "padded message does not fit max_variable_byte_size (lib.rs:90)");
+    hsw::FrameDesc &o = *out;
+    o.input_len = d.input_len; o.first_block = d.first_block;
+    o.prologue_cell = d.prologue_cell; o.epilogue_cell = d.epilogue_cell;
+    o.prologue_lookup = d.prologue_lookup; o.epilogue_lookup = d.epilogue_lookup;
+    o.zero_cell = d.zero_cell; o.n_blocks = d.n_blocks; o.num_round = d.num_round;
+    o.precomputed_round = d.precomputed_round; o.range_check_inputs = d.is_input_range_check ? 1u : 0u;
+    return HSW_OK;
+}
+
 // Checks n frame descriptors and stages them in one of the engine's pinned, device-mapped descriptor
 // buffers (the kernel reads them in place: no H2D copy).  The caller records slot->done after its launch.
 static int stage_frame_descs(hsw_engine *e, const hsw_frame_desc *descs, size_t n, hsw::FrameDesc **d_descs,
@@ -401,19 +417,9 @@ static int stage_frame_descs(hsw_engine *e, const hsw_frame_desc *descs, size_t 
     }
     size_t max_blocks = 0;
     for (size_t i = 0; i < n; i++) {
-        const hsw_frame_desc &d = descs[i];
-        if (d.n_blocks == 0) return set_err(e, HSW_ERR_UNSUPPORTED, "a digest frame needs max_variable_byte_size >= 64");
-        if ((uint64_t)d.num_round != (d.input_len + 9 + 63) / 64)
-            return set_err(e, HSW_ERR_INVALID_ARG, "num_round is not ceil((input_len + 9) / 64) (lib.rs:80-84)");
-        if (d.precomputed_round > d.num_round || d.num_round - d.precomputed_round > d.n_blocks)
-            return set_err(e, HSW_ERR_TOO_LARGE, "padded message does not fit max_variable_byte_size (lib.rs:90)");
-        hsw::FrameDesc &o = slot.h[i];
-        o.input_len = d.input_len; o.first_block = d.first_block;
-        o.prologue_cell = d.prologue_cell; o.epilogue_cell = d.epilogue_cell;
-        o.prologue_lookup = d.prologue_lookup; o.epilogue_lookup = d.epilogue_lookup;
-        o.zero_cell = d.zero_cell; o.n_blocks = d.n_blocks; o.num_round = d.num_round;
-        o.precomputed_round = d.precomputed_round; o.range_check_inputs = d.is_input_range_check ? 1u : 0u;
-        if (d.n_blocks > max_blocks) max_blocks = d.n_blocks;
+        const int rc1 = convert_frame_desc(e, descs[i], &slot.h[i]);
+        if (rc1 != HSW_OK) return rc1;
+        if (descs[i].n_blocks > max_blocks) max_blocks = descs[i].n_blocks;
     }
     int rc = ensure_inv_table(e, max_blocks + 1);
     if (rc != HSW_OK) return rc;
@@ -505,13 +511,22 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
         }
         return rc;
     }
-    // ONE launch: frame waves ride on the small-batch kernel's grid
-    hsw::FrameDesc *d_descs = nullptr;
-    size_t max_blocks = 0;
-    hsw_engine::FrameSlot *slot = nullptr;
-    rc = stage_frame_descs(e, a->descs, a->n_digests, &d_descs, &max_blocks, &slot);
-    if (rc != HSW_OK) return rc;
+    // ONE launch: frame waves ride on the small-batch kernel's grid.  The first descriptor travels by value in
+    // the kernel arguments; only further ones are staged in pinned memory (a single digest -- the reference's
+    // bench circuit -- then needs no staging slot, no event and no read of host memory to get going).
     hsw::SmallFrames fr{};
+    hsw::FrameDesc *d_descs = nullptr;
+    size_t max_blocks = a->descs[0].n_blocks;
+    hsw_engine::FrameSlot *slot = nullptr;
+    if (a->n_digests == 1) {
+        rc = convert_frame_desc(e, a->descs[0], &fr.d0);
+        if (rc == HSW_OK) rc = ensure_inv_table(e, max_blocks + 1);
+        if (rc != HSW_OK) return rc;
+    } else {
+        rc = stage_frame_descs(e, a->descs, a->n_digests, &d_descs, &max_blocks, &slot);
+        if (rc != HSW_OK) return rc;
+        fr.d0 = *slot->h;
+    }
     fr.descs = d_descs;
     fr.inv_tbl = e->d_inv_tbl[(b.flags & HSW_REPR_MONTGOMERY) ? 1 : 0];
     fr.blocks0 = a->d_blocks0;
@@ -521,7 +536,6 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
     fr.n_frames = (uint32_t)a->n_digests;
     fr.byte_waves = (uint32_t)(max_blocks > 32 ? 32 : max_blocks);                  // one wave per 64 input bytes
     fr.state_waves = (uint32_t)((9 * (max_blocks + 1) + 63) / 64 < 4 ? (9 * (max_blocks + 1) + 63) / 64 : 4) + 1;
-    fr.d0 = *slot->h;                                                                // (stage_frame_descs converted it)
     fr.brk = brk;
     uint32_t *host_next = nullptr;
     if (a->host_next_states) {
@@ -537,9 +551,11 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
     }
     rc = hsw_witness_blocks_impl(e, &b, &fr, host_next);
     if (rc != HSW_OK) return rc;
-    hipError_t he = hipEventRecord(slot->done, e->stream);
-    if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
-    slot->inflight = true;
+    if (slot) {
+        hipError_t he = hipEventRecord(slot->done, e->stream);
+        if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "hipEventRecord", he);
+        slot->inflight = true;
+    }
     return HSW_OK;
 } HSW_NO_UNWIND
 
