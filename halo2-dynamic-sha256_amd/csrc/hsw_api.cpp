@@ -275,6 +275,11 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
         e->split = (int)value;
         return HSW_OK;
     }
+    if (std::strcmp(name, "helpers") == 0) {
+        if (value < 0 || value > HSW_SMALL_MAX_HELPERS) return set_err(e, HSW_ERR_INVALID_ARG, "helpers must be 0 (auto) .. 4");
+        e->helpers = (int)value;
+        return HSW_OK;
+    }
     if (std::strcmp(name, "tile") == 0) {
         if (value != 0 && value != 32 && value != 64 && value != 128 && value != 6416)
             return set_err(e, HSW_ERR_INVALID_ARG, "tile must be 0 (auto), 32, 64 or 128");
@@ -459,6 +464,9 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             }
         }
         if (small) {
+            // Montgomery cells: helper waves share each role's conversions (hsw_expand.hpp Em::HELPERS)
+            const uint32_t helpers = !(flags & HSW_REPR_MONTGOMERY) ? 1u : e->helpers ? (uint32_t)e->helpers : 4u;
+            p.parts = helpers;
             p.next_states_host = host_next_states ? host_next_states + 8 * done : nullptr;
             he = hsw::launch_small(p, done == 0 ? frames : nullptr, e->limbs, e->stream);
             if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_small_kernel", he);
@@ -466,7 +474,7 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             li.limbs = 2; li.tile_cells = 128; li.tile_rows = 16;
             li.repr = (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
             li.internals = e->mode == HSW_MODE_HALO2_INTERNALS ? 1u : 0u;
-            li.parts = hsw::HSW_SMALL_WAVES_PER_BLOCK; li.split = 2; li.n_blocks = n;
+            li.parts = hsw::HSW_SMALL_WAVES_PER_BLOCK * helpers; li.split = 2; li.n_blocks = n;
             li.grid = (uint64_t)n * hsw::HSW_SMALL_WAVES_PER_BLOCK + ((done == 0 && frames) ? (uint64_t)frames->n_frames * (frames->state_waves + frames->byte_waves) : 0);
             continue;
         }

@@ -535,7 +535,10 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
     fr.lookup0 = a->d_lookup0;
     fr.n_frames = (uint32_t)a->n_digests;
     fr.byte_waves = (uint32_t)(max_blocks > 32 ? 32 : max_blocks);                  // one wave per 64 input bytes
-    fr.state_waves = (uint32_t)((9 * (max_blocks + 1) + 63) / 64 < 4 ? (9 * (max_blocks + 1) + 63) / 64 : 4) + 1;
+    // state waves: one frame cell per work item (hsw_frame_body.hpp), about two per thread -- each wave repeats the
+    // last block's 64-round recurrence first, so more waves cost SIMDs, not time
+    const size_t state_items = 192 + (size_t)hsw::frame::E_STATE * (max_blocks + 1) + 32 * 11;
+    fr.state_waves = (uint32_t)((state_items + 127) / 128 < 16 ? (state_items + 127) / 128 : 16);
     fr.brk = brk;
     uint32_t *host_next = nullptr;
     if (a->host_next_states) {

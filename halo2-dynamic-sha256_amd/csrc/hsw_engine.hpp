@@ -20,6 +20,7 @@ struct hsw_engine {
     hsw_shape shape{};
     int limbs = 2;
     int parts = 0;             // waves per block; 0 = choose from the batch size
+    int helpers = 0;           // small-batch kernel, Montgomery cells: waves per role, 0 = chosen from the batch size
     int split = -1;            // -1 = small-batch kernel for <= 32 blocks, 0 = never, 1 = one phase per wave (32 waves per
                                // block) in hsw_expand_kernel, 2 = small-batch kernel always
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128

@@ -193,6 +193,10 @@ DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
     return o;
 }
 
+// Lane within the wave.  Workgroups are one wave, except the small-batch kernel's Montgomery instantiation,
+// whose workgroup is up to 8 waves sharing one tile (Em::HELPERS); with __launch_bounds__(64) the mask folds away.
+DEV u32 lane_id() { return threadIdx.x & 63u; }
+
 // ------------------------------------------------------------------ emitter
 // Emission state of one lane.  `row`, `active`, `call`, `unit` are per lane; the
 // rest is wave-uniform.  WHERE a cell goes inside the tile is not state at all:
@@ -200,7 +204,7 @@ DEV Fe8 fe_neg_nonzero(const Fe8 &m) {
 // ds_write_b64 at an immediate offset and every flush point is an `if constexpr`.
 // REPR: 0 = canonical 32-byte cells, 1 = Montgomery 32-byte cells, 2 = compact 8-byte cells
 // (low 64 bits; the negation cells hold x where the field value is -x -- hsw.h HSW_REPR_COMPACT64).
-template <int T, int R, int REPR_, bool RC_, bool NO_REALIGN_ = false>
+template <int T, int R, int REPR_, bool RC_, bool NO_REALIGN_ = false, bool EMITS_ = true>
 struct Em {
     static constexpr int TILE = T, ROWS = R;
     static constexpr int REPR = REPR_;
@@ -214,6 +218,16 @@ struct Em {
     //  tails and heads are not neighbours in the stream.)
     static constexpr bool REALIGN = !NO_REALIGN_ && (REPR_ == 0 || (REPR_ == 1 && RC_));
     static constexpr int STRIDE = REALIGN ? T + 3 : T + 1;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
+    // Helper waves (small-batch kernel, Montgomery cells): the workgroup is hcnt waves sharing one tile; each
+    // converts and stores every hcnt-th 64-cell run of a flush -- the conversion is two thirds of a wave's
+    // instructions in a launch paced by exactly that.  hsel = this wave's index.  Wave 0 is the emitter; the
+    // others run the same program instantiated with EMITS = false: nothing is staged, so the compiler drops
+    // the arithmetic and what remains is the role's sequence of flushes (barrier, convert a share, barrier).
+    // (Helper waves as extra workgroups were slower beyond 2: workgroup dispatch, ~5 ns each, paces the launch;
+    //  helpers that repeat the emission, 27 vs 32 us per 16 blocks: the VALUs of 592 workgroups are the bound.)
+    static constexpr bool EMITS = EMITS_;
+    static constexpr bool HELPERS = NO_REALIGN_ && REPR_ == 1;
+    u32 hsel, hcnt;
     u64 *row0;         // this lane's tile row (LDS), column 0
     u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
     u32 carry_neg;     // bit j: carried column j holds a field negation
@@ -268,6 +282,17 @@ DEV u32 packed_cell(const EM &em, u32 cl) {       // FlexGate column packing: ad
 DEV void store16(char *base, u32 byte_off, uint4 v) { *reinterpret_cast<uint4 *>(base + (size_t)byte_off) = v; }
 DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base + (size_t)byte_off) = v; }
 
+// Gate cell -> Montgomery form.  Where the VALUs are the bound (helper-wave launches) a run of 64 cells with
+// nothing above 2^32 -- most runs -- takes the one-multiplicand conversion (wave-uniform choice); in the
+// HBM-bound kernel the switch bought nothing.
+template <class EM>
+DEV Fe8 mont_cell(u64 v) {
+    if constexpr (EM::HELPERS) {
+        if (__builtin_amdgcn_ballot_w64((u32)(v >> 32) != 0u) == 0ull) return mont_from_u64<false>((u32)v, 0u);
+    }
+    return mont_from_u64<true>((u32)v, (u32)(v >> 32));
+}
+
 // Realignment.  HBM writes run at full rate only when every contiguous run covers whole
 // 128-byte lines (measured: a stream starting 32 / 64 / 96 bytes past a line boundary runs
 // 47 / 26 / 47 % slower, tools/align_probe.py) -- but where a block's stream starts is dictated
@@ -280,7 +305,7 @@ template <class EM, bool FULL>
 DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, bool cn) {
     constexpr int T = EM::TILE;
     constexpr int S = EM::STRIDE;
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     char *base = reinterpret_cast<char *>(em.out);
     const u32 skew = EM::REALIGN ? em.skew : 0u;
     // FlexGate column breaks inside this block (wave-uniform; none unless a pack plan is in force): a flush
@@ -358,13 +383,14 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                     for (u32 q = 0; lane + q < ncells; q += 64)
                         store8(base, (packed ? packed_cell(em, cl0 + q) : cl0 + q + shift) * 8u, src[q]);
             } else if constexpr (EM::MONT) {
-                const u64 *src = em.tile + lane;
-                u32 cl0 = em.cell_base + seg + lane;
-                for (u32 r = 0; r < em.nrows; r++, src += S, cl0 += em.unit_cells)
+                const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;    // rows dealt to the helper waves
+                const u64 *src = em.tile + lane + hs * S;
+                u32 cl0 = em.cell_base + seg + lane + hs * em.unit_cells;
+                for (u32 r = hs; r < em.nrows; r += hn, src += hn * S, cl0 += hn * em.unit_cells)
                     for (u32 q = 0; lane + q < ncells; q += 64) {
                         const u32 off = (packed ? packed_cell(em, cl0 + q) : cl0 + q + shift) * 32u - q * 32u;
                         const u64 v = src[q];
-                        Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
+                        Fe8 m = mont_cell<EM>(v);
                         if (any_neg) {
                             if (is_neg(lane + q) && v != 0ull) m = fe_neg_nonzero(m);
                         }
@@ -416,12 +442,13 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
             // full tiles index by the compile-time T (a shift) and skip the < 4 empty / held-back columns
             // of a skewed unit's first tile; partial ones divide by the run length
             const u32 total = FULL ? em.nrows * (u32)T : total_cells;
-            for (u32 i = lane; i < total; i += 64) {
+            const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;        // 64-cell runs dealt to the helper waves
+            for (u32 i = lane + 64u * hs; i < total; i += 64u * hn) {
                 const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = FULL ? i % (u32)T : lo0 + i - r * ncols;
                 if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
                 const u64 v = em.tile[r * S + p];
-                Fe8 m = mont_from_u64<true>((u32)v, (u32)(v >> 32));
+                Fe8 m = mont_cell<EM>(v);
                 if (any_neg) {                        // compile-time false for most tiles
                     if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
                 }
@@ -498,7 +525,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
 
 template <class EM, class C>
 DEV auto emit(C, EM &em, u64 v) {
-    em.row[C::pos] = v;
+    if constexpr (EM::EMITS) em.row[C::pos] = v;
     if constexpr (C::pos + 1 == EM::TILE) {
         flush_tile<EM, true>(em, EM::TILE, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
         constexpr int T3 = EM::TILE - 3;
@@ -527,7 +554,7 @@ DEV void part_units(u32 part, u32 parts, u32 n_units, u32 &unit_lo, u32 &nrows) 
 }
 // Unit expanded by this lane (idle lanes shadow the last active one).
 DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     u32 nrows, unit_lo;
     part_units(part, parts, n_units, unit_lo, nrows);
     return (nrows ? unit_lo : 0u) + (lane < nrows ? lane : (nrows ? nrows - 1 : 0));
@@ -538,7 +565,7 @@ DEV u32 lane_unit(u32 part, u32 parts, u32 n_units) {
 template <class EM>
 DEV bool phase_begin(EM &em, u32 part, u32 parts, u32 n_units, u32 unit_cells, u32 phase_off,
                      u32 call_base, u32 calls_per_unit, u32 lk_base = 0, u32 lk_per_unit = 0) {
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     u32 nrows, unit_lo;
     part_units(part, parts, n_units, unit_lo, nrows);
     if (nrows == 0) unit_lo = 0;
@@ -580,7 +607,7 @@ DEV void flush_chip(const EM &em, const ExpandParams &p, u64 block_first_limb) {
     constexpr u32 MASK = (1u << B) - 1u;
     if (em.calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
     __syncthreads();                                                   // d16 staged by all lanes
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     const u64 ncols = p.ncols;
     const u64 first = block_first_limb + (u64)em.call_first * L;       // first limb call of this run
     const u64 last = first + (u64)em.calls * L - 1;
@@ -636,7 +663,7 @@ template <class EM>
 DEV void flush_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_base) {
     if (em.lks == 0 || p.lookup == nullptr) return;
     __syncthreads();
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     uint4 *out = reinterpret_cast<uint4 *>(p.lookup) + (lookup_block_base + em.lk_first) * 2u;
     if constexpr (EM::COMPACT) {
         u64 *out64 = reinterpret_cast<u64 *>(p.lookup) + lookup_block_base + em.lk_first;
@@ -670,7 +697,8 @@ DEV void phase_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_
 template <class EM>
 DEV void lookup16(EM &em, u32 v) {
     if constexpr (EM::RC) {
-        if (em.active) em.lk16[em.lk] = (u16)v;
+        if constexpr (EM::EMITS)
+            if (em.active) em.lk16[em.lk] = (u16)v;
         em.lk++;
     }
 }
@@ -751,7 +779,8 @@ DEV auto spread_limbs_acc(C c, EM &em, u32 dense, u32 acc, u32 &result) {       
 }
 template <int L, class EM, class C>
 DEV auto sc_spread(C c, EM &em, u32 dense, u32 &spread_out) {
-    if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced by flush_chip
+    if constexpr (EM::EMITS)
+        if (em.active) em.d16[em.call] = (u16)dense;   // chip cells are produced by flush_chip
     em.call++;
     auto c1 = spread_limbs_lw<L, 0>(c, em, dense);
     auto c2 = spread_limbs_sum<L, 0>(c1, em, dense, 0u);
@@ -1015,7 +1044,7 @@ __global__ __launch_bounds__(64) void hsw_expand_kernel(ExpandParams p) {
     __shared__ u16 s_lk16[RC ? R * LY::LK_ROUND : 1];   // lookup-column staging (internals mode only)
 
     HSW_STAMP(0);
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     const u32 parts = p.parts;                   // waves per block (power of two <= 16)
     const size_t blk = blockIdx.x / parts;
     const u32 part = blockIdx.x % parts;

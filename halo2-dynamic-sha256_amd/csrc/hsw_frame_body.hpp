@@ -76,6 +76,11 @@ struct Out {
     DEV void cell_signed(u64 at, bool neg, u64 mag) const { put(gate, place(at), fe_signed<MONT>(neg, mag)); }
     DEV void cell_fe(u64 at, const Fe8 &v) const { put(gate, place(at), v); }
     DEV void look(u64 at, u64 v) const { if (lookup) put(lookup, at, fe_small<MONT>(v)); }
+    // one conversion site for a gate cell or a lookup-column entry (divergent callers pay for it once)
+    DEV void any(bool is_look, u64 at, bool neg, u64 mag) const {
+        if (is_look && !lookup) return;
+        put(is_look ? lookup : gate, is_look ? at : place(at), fe_signed<MONT>(neg, mag));
+    }
     // range_check(byte, 8): lookup byte; [0, byte, 2^8, byte * 2^8]; lookup the product
     DEV void range_check8(u64 at, u64 lk, u32 byte) const {
         cell(at, 0); cell(at + 1, byte); cell(at + 2, 256); cell(at + 3, (u64)byte << 8);
@@ -102,43 +107,113 @@ DEV void frame_cells(const FrameDesc &d, const uint8_t *blocks, const u64 *inv_t
     const u64 max_bytes = (u64)N * 64u;
     const u32 target = d.num_round - d.precomputed_round;               // lib.rs:147-151
     const uint8_t *bytes = blocks + 64 * d.first_block;
-    // ---- prologue, fixed part: lib.rs:124-165; work item t < 46 writes cell t, item 64 the fixed lookups
-    //      and the zero cell (items 128..159: the digest bytes, below) ----
-    for (u32 tid = (parts & FRAME_STATES) ? gtid : 192u; tid < 192u; tid += nthreads) {
-        const u64 len = d.input_len, nr = d.num_round, pre = d.precomputed_round;
-        const u64 padded = 64 * nr, with9 = len + 9, pad = padded - with9;      // pad < 64 (lib.rs:142-144; host-checked)
-        // is_less_than_safe(padding_size, 64)
-        const u64 shift_a = pad + 65536, shifted = shift_a - 64;
-        const u64 limb0 = shifted & 0xffff, limb1 = shifted >> 16;              // limb1 = 0 <=> pad < 64
-        const u64 z = limb1 == 0 ? 1 : 0;
-        if (tid < P_STATE) {
-            u64 v = 0;
-            switch (tid) {
-                case P_LEN: v = len; break;
-                case P_NROUND: v = nr; break;
-                case P_MUL: v = 0; break;      case P_MUL + 1: v = nr; break;     case P_MUL + 2: v = 64; break;  case P_MUL + 3: v = padded; break;
-                case P_ADD: v = len; break;    case P_ADD + 1: v = 9; break;      case P_ADD + 2: v = 1; break;   case P_ADD + 3: v = with9; break;
-                case P_SUB: v = pad; break;    case P_SUB + 1: v = with9; break;  case P_SUB + 2: v = 1; break;   case P_SUB + 3: v = padded; break;
-                case P_LT: v = shifted; break; case P_LT + 1: v = 64; break;      case P_LT + 2: v = 1; break;    case P_LT + 3: v = shift_a; break;
-                case P_LT + 4: v = 65536; break;   /* written as -2^16 below */   case P_LT + 5: v = 1; break;    case P_LT + 6: v = pad; break;
-                case P_RC32: v = limb0; break; case P_RC32 + 1: v = limb1; break; case P_RC32 + 2: v = 65536; break; case P_RC32 + 3: v = shifted; break;
-                case P_ISZ: v = z; break;      case P_ISZ + 1: v = limb1; break;
-                case P_ISZ + 2: v = 1; break;  // is_zero's inv witness of 0 is 1
-                case P_ISZ + 3: v = 1; break;  case P_ISZ + 4: v = 0; break;      case P_ISZ + 5: v = limb1; break;
-                case P_ISZ + 6: v = z; break;  case P_ISZ + 7: v = 0; break;
-                case P_PRE: v = pre; break;
-                case P_TGT: v = nr - pre; break; case P_TGT + 1: v = pre; break;  case P_TGT + 2: v = 1; break;   case P_TGT + 3: v = nr; break;
-                default: break;
+    // ---- everything that looks at a state word, ONE CELL per work item and one conversion site for all of
+    //      them (a wave's lanes sit in different halo2-base calls; dealt call by call, the lanes of the
+    //      longest call -- 12 cells, ~200 instructions each in Montgomery form -- held the whole launch up):
+    //        [0, 192)                  prologue, fixed part: lib.rs:124-165; item t < 46 = cell t, item 64 = the
+    //                                  fixed lookups and the zero cell
+    //        [192, +76 (N + 1))        epilogue, state selection: lib.rs:294-310; candidate n = j / 76, cell j % 76:
+    //                                  is_equal(n, target) (12 cells), then select of word i (8 cells each)
+    //        [.., +32 * 11)            epilogue, digest bytes: lib.rs:311-341; (word, byte) = j / 11, cell j % 11:
+    //                                  the byte, range_check 8 (4 cells), the mul_add (4 cells), 2 lookup entries
+    const u32 n_sel = (u32)E_STATE * (N + 1), n_items = 192u + n_sel + 32u * 11u;
+    const u64 len = d.input_len, nr = d.num_round, pre = d.precomputed_round;
+    const u64 padded = 64 * nr, with9 = len + 9, pad = padded - with9;          // pad < 64 (lib.rs:142-144; host-checked)
+    // is_less_than_safe(padding_size, 64)
+    const u64 shift_a = pad + 65536, shifted = shift_a - 64;
+    const u64 limb0 = shifted & 0xffff, limb1 = shifted >> 16;                  // limb1 = 0 <=> pad < 64
+    const u64 z = limb1 == 0 ? 1 : 0;
+    for (u32 t = (parts & FRAME_STATES) ? gtid : n_items; t < n_items; t += nthreads) {
+        bool is_look = false, neg = false;
+        u64 at = 0, v = 0;
+        if (t < 192u) {
+            const u32 tid = t;
+            if (tid < P_STATE) {
+                switch (tid) {
+                    case P_LEN: v = len; break;
+                    case P_NROUND: v = nr; break;
+                    case P_MUL: v = 0; break;      case P_MUL + 1: v = nr; break;     case P_MUL + 2: v = 64; break;  case P_MUL + 3: v = padded; break;
+                    case P_ADD: v = len; break;    case P_ADD + 1: v = 9; break;      case P_ADD + 2: v = 1; break;   case P_ADD + 3: v = with9; break;
+                    case P_SUB: v = pad; break;    case P_SUB + 1: v = with9; break;  case P_SUB + 2: v = 1; break;   case P_SUB + 3: v = padded; break;
+                    case P_LT: v = shifted; break; case P_LT + 1: v = 64; break;      case P_LT + 2: v = 1; break;    case P_LT + 3: v = shift_a; break;
+                    case P_LT + 4: v = 65536; break;   /* written as -2^16 */         case P_LT + 5: v = 1; break;    case P_LT + 6: v = pad; break;
+                    case P_RC32: v = limb0; break; case P_RC32 + 1: v = limb1; break; case P_RC32 + 2: v = 65536; break; case P_RC32 + 3: v = shifted; break;
+                    case P_ISZ: v = z; break;      case P_ISZ + 1: v = limb1; break;
+                    case P_ISZ + 2: v = 1; break;  // is_zero's inv witness of 0 is 1
+                    case P_ISZ + 3: v = 1; break;  case P_ISZ + 4: v = 0; break;      case P_ISZ + 5: v = limb1; break;
+                    case P_ISZ + 6: v = z; break;  case P_ISZ + 7: v = 0; break;
+                    case P_PRE: v = pre; break;
+                    case P_TGT: v = nr - pre; break; case P_TGT + 1: v = pre; break;  case P_TGT + 2: v = 1; break;   case P_TGT + 3: v = nr; break;
+                    default: break;
+                }
+                at = P0 + tid; neg = tid == P_LT + 4;
+            } else if (tid < P_BYTES) {
+                at = P0 + tid; v = state_word(0, tid - P_STATE);                 // lib.rs:162-165
+            } else if (tid >= 64u && tid < 67u) {
+                is_look = true; at = d.prologue_lookup + (tid - 64u);
+                v = tid == 64u ? pad : tid == 65u ? limb0 : limb1;
+            } else if (tid == 67u && d.zero_cell != ~0ull) {
+                at = d.zero_cell; v = 0;                                         // Context.zero_cell
+            } else {
+                continue;
             }
-            o.cell_signed(P0 + tid, tid == P_LT + 4, v);
-        } else if (tid < P_BYTES) {
-            o.cell(P0 + tid, state_word(0, tid - P_STATE));                      // lib.rs:162-165
-        } else if (tid == 64) {
-            o.look(d.prologue_lookup, pad);
-            o.look(d.prologue_lookup + 1, limb0);
-            o.look(d.prologue_lookup + 2, limb1);
-            if (d.zero_cell != ~0ull) o.cell(d.zero_cell, 0);                   // Context.zero_cell
+        } else if (t < 192u + n_sel) {
+            const u32 j = t - 192u, n = j / (u32)E_STATE, k = j % (u32)E_STATE;
+            const bool sel = n == target;
+            at = E0 + j;
+            if (k < 12u) {                                                       // is_equal(n, target)
+                const bool lt = n < target;
+                const u64 mag = lt ? target - n : n - target;
+                if (k == 6u && !sel) {                                           // (n - target)^-1 = -(target - n)^-1
+                    const Fe8 inv = fe_load(inv_tbl + 4 * mag);
+                    o.cell_fe(at, lt ? fe_neg_nonzero(inv) : inv);
+                    continue;
+                }
+                switch (k) {
+                    case 0: case 5: case 9: neg = lt; v = mag; break;
+                    case 1: case 6: case 7: v = 1; break;
+                    case 2: v = target; break;
+                    case 3: v = n; break;
+                    case 4: case 10: v = sel ? 1 : 0; break;
+                    default: v = 0; break;                                       // 8, 11
+                }
+            } else {                                                             // select of word i
+                const u32 i = (k - 12u) / 8u, q = (k - 12u) % 8u;
+                const u64 a = state_word(n, i);                                  // assigned_state[i]
+                const u64 b = n > target ? state_word(target, i) : 0;            // output_h_out[i] so far
+                const bool lt = a < b;
+                const u64 mag = lt ? b - a : a - b;
+                switch (q) {
+                    case 0: case 6: neg = lt; v = mag; break;
+                    case 1: v = 1; break;
+                    case 2: case 4: v = b; break;
+                    case 3: v = a; break;
+                    case 5: v = sel ? 1 : 0; break;
+                    default: v = sel ? a : b; break;                             // 7
+                }
+            }
+        } else {
+            const u32 j = t - 192u - n_sel, wi = j / 11u, c = j % 11u, w = wi / 4u, idx = wi % 4u;
+            const u32 word = target <= N ? state_word(target, w) : 0;
+            const u64 e = E0 + (u64)E_STATE * (N + 1) + (u64)E_WORD * w;
+            const u32 byte = (word >> (24 - 8 * idx)) & 0xffu;
+            const u32 sum_before = idx == 0 ? 0 : (word >> (32 - 8 * idx)) << (32 - 8 * idx);
+            // range_check(byte, 8): lookup byte; [0, byte, 2^8, byte * 2^8]; lookup the product
+            switch (c) {
+                case 0: at = e + 5 * idx; v = byte; break;
+                case 1: at = e + 5 * idx + 1; v = 0; break;
+                case 2: at = e + 5 * idx + 2; v = byte; break;
+                case 3: at = e + 5 * idx + 3; v = 256; break;
+                case 4: at = e + 5 * idx + 4; v = (u64)byte << 8; break;
+                case 5: at = e + 20 + 4 * idx; v = sum_before; break;
+                case 6: at = e + 20 + 4 * idx + 1; v = byte; break;
+                case 7: at = e + 20 + 4 * idx + 2; v = 1ull << (24 - 8 * idx); break;
+                case 8: at = e + 20 + 4 * idx + 3; v = (u64)sum_before + ((u64)byte << (24 - 8 * idx)); break;
+                case 9: is_look = true; at = d.epilogue_lookup + 8 * w + 2 * idx; v = byte; break;
+                default: is_look = true; at = d.epilogue_lookup + 8 * w + 2 * idx + 1; v = (u64)byte << 8; break;
+            }
         }
+        o.any(is_look, at, neg, v);
     }
 
     // ---- prologue, input bytes: lib.rs:170-178 ----
@@ -149,50 +224,6 @@ DEV void frame_cells(const FrameDesc &d, const uint8_t *blocks, const u64 *inv_t
             o.range_check8(P0 + P_BYTES + max_bytes + 4 * i, d.prologue_lookup + P_FIXED_LOOKUPS + 2 * i, b);
     }
 
-    // ---- epilogue, state selection: lib.rs:294-310 ----
-    // work item j: candidate n = j / 9; part 0 = is_equal(n, target), parts 1..8 = select of word part - 1
-    for (u32 j = (parts & FRAME_STATES) ? gtid : 9u * (N + 1); j < 9u * (N + 1); j += nthreads) {
-        const u32 n = j / 9u, part = j % 9u;
-        const u64 at = E0 + (u64)E_STATE * n;
-        const bool sel = n == target;
-        if (part == 0) {
-            const bool neg = n < target;
-            const u64 mag = neg ? target - n : n - target;
-            o.cell_signed(at, neg, mag); o.cell(at + 1, 1); o.cell(at + 2, target); o.cell(at + 3, n);
-            o.cell(at + 4, sel ? 1 : 0); o.cell_signed(at + 5, neg, mag);
-            if (sel) o.cell(at + 6, 1);
-            else {
-                const Fe8 inv = fe_load(inv_tbl + 4 * mag);                     // (n - target)^-1 = -(target - n)^-1
-                o.cell_fe(at + 6, neg ? fe_neg_nonzero(inv) : inv);
-            }
-            o.cell(at + 7, 1); o.cell(at + 8, 0); o.cell_signed(at + 9, neg, mag);
-            o.cell(at + 10, sel ? 1 : 0); o.cell(at + 11, 0);
-        } else {
-            const u32 i = part - 1;
-            const u64 a = state_word(n, i);                                     // assigned_state[i]
-            const u64 b = n > target ? state_word(target, i) : 0;               // output_h_out[i] so far
-            const u64 s = at + 12 + 8 * i;
-            const bool neg = a < b;
-            const u64 mag = neg ? b - a : a - b;
-            o.cell_signed(s, neg, mag); o.cell(s + 1, 1); o.cell(s + 2, b); o.cell(s + 3, a);
-            o.cell(s + 4, b); o.cell(s + 5, sel ? 1 : 0); o.cell_signed(s + 6, neg, mag);
-            o.cell(s + 7, sel ? a : b);
-        }
-    }
-
-    // ---- epilogue, digest bytes: lib.rs:311-341 ----
-    for (u32 tid = (parts & FRAME_STATES) ? 128u + gtid : 160u; tid < 160u; tid += nthreads) {
-        const u32 w = (tid - 128) / 4, idx = (tid - 128) % 4;
-        const u32 word = target <= N ? state_word(target, w) : 0;
-        const u64 at = E0 + (u64)E_STATE * (N + 1) + (u64)E_WORD * w;
-        const u32 byte = (word >> (24 - 8 * idx)) & 0xffu;
-        o.cell(at + 5 * idx, byte);
-        o.range_check8(at + 5 * idx + 1, d.epilogue_lookup + 8 * w + 2 * idx, byte);
-        const u32 sum_before = idx == 0 ? 0 : (word >> (32 - 8 * idx)) << (32 - 8 * idx);
-        const u64 m = at + 20 + 4 * idx;
-        o.cell(m, sum_before); o.cell(m + 1, byte); o.cell(m + 2, 1ull << (24 - 8 * idx));
-        o.cell(m + 3, (u64)sum_before + ((u64)byte << (24 - 8 * idx)));
-    }
 }
 
 }  // namespace framedev

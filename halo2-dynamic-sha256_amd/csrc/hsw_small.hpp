@@ -107,7 +107,7 @@ DEV u32 lane_get(u32 v, u32 src_lane) { return (u32)__builtin_amdgcn_ds_bpermute
 template <class EM>
 DEV void sub_begin(EM &em, u32 unit_lo, u32 nrows, u32 unit_cells, u32 phase_off, u32 sub_off, u32 sub_calls,
                    u32 sub_lk) {
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     em.nrows = nrows;
     em.unit_cells = unit_cells;                     // row stride in the stream
     em.cell_base = phase_off + unit_lo * unit_cells + sub_off;
@@ -130,7 +130,7 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
     constexpr u32 MASK = (1u << B) - 1u;
     if (sub_calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
     __syncthreads();                                                   // d16 staged by all lanes
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     const u32 per_row = sub_calls * (u32)L, total = em.nrows * per_row;
     // one 64-bit division per wave (scalar), 32-bit ones per limb: limb n0 + x sits in column (c0 + x) % ncols
     // at row r0 + (c0 + x) / ncols, x < 2^17
@@ -139,7 +139,8 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
     const u32 c0 = (u32)(n0 - r0 * p.ncols), ncols = p.ncols;
     const size_t rbase = (size_t)(r0 - p.cursor0 / p.ncols);
     constexpr u32 CB = EM::COMPACT ? 8u : 32u;
-    for (u32 k = lane; k < total; k += 64) {
+    const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;
+    for (u32 k = lane + 64u * hs; k < total; k += 64u * hn) {
         const u32 r = k / per_row, j = k - r * per_row;
         const u32 limb = ((u32)em.d16[r * sub_calls + j / (u32)L] >> (B * (j % (u32)L))) & MASK;
         const u32 x = c0 + r * calls_per_unit * (u32)L + j;
@@ -172,9 +173,10 @@ DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block
                         u32 sub_lk) {
     if (sub_lk == 0 || p.lookup == nullptr) return;
     __syncthreads();
-    const u32 lane = threadIdx.x;
+    const u32 lane = lane_id();
     const u32 total = em.nrows * sub_lk;
-    for (u32 k = lane; k < total; k += 64) {
+    const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;
+    for (u32 k = lane + 64u * hs; k < total; k += 64u * hn) {
         const u32 r = k / sub_lk, j = k - r * sub_lk;
         const u32 v = em.lk16[k];
         const size_t at = lookup_block_base + lk0 + r * lk_per_unit + j;
@@ -203,105 +205,13 @@ DEV void sub_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t 
     if constexpr (EM::RC) scatter_lookup(em, p, lookup_block_base, lk0, lk_per_unit, sub_lk);
 }
 
-template <int L, int REPR, bool RC>
-__global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFrames fr) {
+// One role's program (kernel below): EM is the emitter type, or its EMITS = false twin for helper waves.
+template <int L, int REPR, bool RC, class EM>
+DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], size_t blk, u32 role, u64 *s_tile,
+                    u16 *s_d16, u16 *s_lk16) {
     using LY = Lay<L, RC>;
     using SP = SmallPlan<L, RC>;
-    using EM = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true>;
-    __shared__ u64 s_tile[(SMALL_ROWS + 1) * EM::STRIDE];                   // +1 scratch row for lanes >= 16
-    __shared__ u16 s_d16[SMALL_ROWS * SP::MAX_CALLS];
-    __shared__ u16 s_lk16[RC ? SMALL_ROWS * SP::MAX_LK : 1];
-    HSW_STAMP(0);
-    const u32 lane = threadIdx.x;
-    const u32 n_expand = (u32)p.n_blocks * SMALL_ROLES;
-
-    // ---- frame waves (whole-digest launches): hsw_frame_body.hpp ------------------------------------
-    if constexpr (RC && REPR != 2) {
-        if (blockIdx.x >= n_expand) {
-            const u32 wpf = fr.state_waves + fr.byte_waves;
-            const u32 fw = blockIdx.x - n_expand, fi = fw / wpf, slice = fw % wpf;
-            const FrameDesc d = fi == 0u ? fr.d0 : fr.descs[fi];
-            uint4 *gate = reinterpret_cast<uint4 *>(fr.gate0), *lookup = reinterpret_cast<uint4 *>(fr.lookup0);
-            const u64 *inv = reinterpret_cast<const u64 *>(fr.inv_tbl);
-            if (slice >= fr.state_waves) {       // the input-byte cells: lib.rs:170-178
-                framedev::frame_cells<REPR == 1>(d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_BYTES,
-                                                 (slice - fr.state_waves) * 64u + lane, fr.byte_waves * 64u,
-                                                 [](u32, u32) -> u32 { return 0u; });
-                HSW_STAMP(4);
-                return;
-            }
-            // candidate state n >= 1 = output of block n - 1 = pre-state of block n (the chain inputs); the
-            // last block's output comes from the recurrence itself, computed here
-            const u32 *ps0 = fr.pre0 + 8 * d.first_block, *ps_last = ps0 + 8 * (d.n_blocks - 1);
-            // (the pre-states may sit in pinned host memory: fetch them now, they arrive while the chain runs)
-            __shared__ u32 s_states[8 * 34];             // a small-batch launch has at most 32 blocks
-            const u32 nw = 8u * d.n_blocks;
-            u32 pre_w[4];
-#pragma unroll
-            for (u32 k = 0; k < 4; k++) pre_w[k] = lane + 64u * k < nw ? ps0[lane + 64u * k] : 0u;
-            u32 lA, lE, lW;
-            chain_latch<true>(reinterpret_cast<const u32 *>(fr.blocks0 + 64 * (d.first_block + d.n_blocks - 1)), ps_last,
-                              64, 64 - (int)(lane & 3u), -1, lA, lE, lW);
-#pragma unroll
-            for (u32 k = 0; k < 4; k++) if (lane + 64u * k < nw) s_states[lane + 64u * k] = pre_w[k];
-            if (lane < 8) s_states[nw + lane] = ps_last[lane] + (lane < 4 ? lA : lE);   // compression.rs:197-212
-            __syncthreads();
-            HSW_STAMP(1);
-            framedev::frame_cells<REPR == 1>(
-                d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_STATES, slice * 64u + lane, fr.state_waves * 64u,
-                [&](u32 n, u32 i) -> u32 { return s_states[8u * n + i]; });
-            HSW_STAMP(4);
-            return;
-        }
-    }
-
-    const size_t blk = blockIdx.x / SMALL_ROLES;
-    const u32 role = blockIdx.x % SMALL_ROLES;
-    const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
-    u32 ps[8];                                   // this block's pre-state (wave-uniform)
-    if (p.flags & HSW_K_CHAINED) {
-        // ONE message: pre_states holds its initial state only; block b's pre-state is b compressions away
-        // (the roles that never look at the state skip the walk)
-#pragma unroll
-        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[i];
-        const bool needs_state = role < SMALL_ROUND_ROLES || role == SMALL_ROLE_FEED || role == SMALL_ROLE_STATE;
-        if (needs_state && blk != 0) {
-            // the message schedules of the blocks before this one do not depend on the state: lane l expands
-            // block l's (all at once), K + W goes through LDS (the tile is not in use yet; rows 65 words apart:
-            // no bank conflicts), and only the 64-round recurrence of each block remains serial
-            u32 *s_kw = reinterpret_cast<u32 *>(s_tile);
-            static_assert(sizeof(s_tile) >= 32 * 65 * 4, "K + W of 31 blocks must fit the tile");
-            if (lane < (u32)blk) {
-                const u32 *bl = reinterpret_cast<const u32 *>(p.blocks + 64 * (size_t)lane);
-                u32 w[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(bl[j]);
-#pragma unroll
-                for (int t = 0; t < 64; t++) {
-                    if (t >= 16)
-                        w[t & 15] = w[t & 15] + sha_s0(w[(t + 1) & 15]) + w[(t + 9) & 15] + sha_s1(w[(t + 14) & 15]);
-                    s_kw[lane * 65u + (u32)t] = w[t & 15] + K256[t];
-                }
-            }
-            __syncthreads();
-            for (u32 b = 0; b < (u32)blk; b++) {
-                u32 a = ps[0], bb = ps[1], c = ps[2], d = ps[3], e = ps[4], f = ps[5], g = ps[6], h = ps[7];
-                const u32 *kw = s_kw + b * 65u;
-#pragma unroll 16
-                for (int t = 0; t < 64; t++) {
-                    const u32 t1 = h + kw[t] + sha_S1(e) + sha_ch(e, f, g);
-                    const u32 t2 = sha_S0(a) + sha_maj(a, bb, c);
-                    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
-                }
-                ps[0] += a; ps[1] += bb; ps[2] += c; ps[3] += d; ps[4] += e; ps[5] += f; ps[6] += g; ps[7] += h;
-            }
-            __syncthreads();                       // the tile takes the memory over
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[8 * blk + i];
-    }
-
+    const u32 lane = lane_id();
     EM em;
     em.lk16 = s_lk16;
     em.tile = s_tile;
@@ -311,6 +221,8 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
     em.carry_neg = 0;
     em.head = nullptr;
     em.d16 = s_d16;
+    em.hsel = EM::HELPERS ? threadIdx.x >> 6 : 0u;          // Montgomery launches: blockDim.x / 64 waves share the role
+    em.hcnt = EM::HELPERS ? blockDim.x >> 6 : 1u;
 
     {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
         u64 first = (u64)blk * (u64)LY::GATE_CELLS;
@@ -434,7 +346,7 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
 #pragma unroll
         for (int i = 1; i < 8; i++) fy = (lane & 7u) == (u32)i ? ps[i] : fy;
         const u32 fx = lane < 4 ? lA : lE;
-        if (lane < 8) {
+        if (lane < 8 && em.hsel == 0u) {
             if (p.next_states != nullptr) p.next_states[8 * blk + lane] = fy + fx;
             if (p.next_states_host != nullptr) p.next_states_host[8 * blk + lane] = fy + fx;
         }
@@ -483,18 +395,133 @@ __global__ __launch_bounds__(64) void hsw_small_kernel(ExpandParams p, SmallFram
         }
         HSW_STAMP(3);
     }
+}
+
+template <int L, int REPR, bool RC>
+__global__ __launch_bounds__(REPR == 1 ? 64 * HSW_SMALL_MAX_HELPERS : 64) void hsw_small_kernel(ExpandParams p, SmallFrames fr) {
+    using SP = SmallPlan<L, RC>;
+    using EM = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true>;
+    __shared__ u64 s_tile[(SMALL_ROWS + 1) * EM::STRIDE];                   // +1 scratch row for lanes >= 16
+    __shared__ u16 s_d16[SMALL_ROWS * SP::MAX_CALLS];
+    __shared__ u16 s_lk16[RC ? SMALL_ROWS * SP::MAX_LK : 1];
+    HSW_STAMP(0);
+    const u32 lane = lane_id();
+    const u32 n_expand = (u32)p.n_blocks * SMALL_ROLES;
+
+    // ---- frame waves (whole-digest launches): hsw_frame_body.hpp ------------------------------------
+    if constexpr (RC && REPR != 2) {
+        if (blockIdx.x >= n_expand) {
+            if (EM::HELPERS && threadIdx.x >= 64u) return;       // (frame workgroups use their first wave only)
+            const u32 wpf = fr.state_waves + fr.byte_waves;
+            const u32 fw = blockIdx.x - n_expand, fi = fw / wpf, slice = fw % wpf;
+            const FrameDesc d = fi == 0u ? fr.d0 : fr.descs[fi];
+            uint4 *gate = reinterpret_cast<uint4 *>(fr.gate0), *lookup = reinterpret_cast<uint4 *>(fr.lookup0);
+            const u64 *inv = reinterpret_cast<const u64 *>(fr.inv_tbl);
+            if (slice >= fr.state_waves) {       // the input-byte cells: lib.rs:170-178
+                framedev::frame_cells<REPR == 1>(d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_BYTES,
+                                                 (slice - fr.state_waves) * 64u + lane, fr.byte_waves * 64u,
+                                                 [](u32, u32) -> u32 { return 0u; });
+                HSW_STAMP(4);
+                return;
+            }
+            // candidate state n >= 1 = output of block n - 1 = pre-state of block n (the chain inputs); the
+            // last block's output comes from the recurrence itself, computed here
+            const u32 *ps0 = fr.pre0 + 8 * d.first_block, *ps_last = ps0 + 8 * (d.n_blocks - 1);
+            // (the pre-states may sit in pinned host memory: fetch them now, they arrive while the chain runs)
+            __shared__ u32 s_states[8 * 34];             // a small-batch launch has at most 32 blocks
+            const u32 nw = 8u * d.n_blocks;
+            u32 pre_w[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) pre_w[k] = lane + 64u * k < nw ? ps0[lane + 64u * k] : 0u;
+            u32 lA, lE, lW;
+            chain_latch<true>(reinterpret_cast<const u32 *>(fr.blocks0 + 64 * (d.first_block + d.n_blocks - 1)), ps_last,
+                              64, 64 - (int)(lane & 3u), -1, lA, lE, lW);
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) if (lane + 64u * k < nw) s_states[lane + 64u * k] = pre_w[k];
+            if (lane < 8) s_states[nw + lane] = ps_last[lane] + (lane < 4 ? lA : lE);   // compression.rs:197-212
+            __syncthreads();
+            HSW_STAMP(1);
+            framedev::frame_cells<REPR == 1>(
+                d, fr.blocks0, inv, gate, lookup, fr.brk, framedev::FRAME_STATES, slice * 64u + lane, fr.state_waves * 64u,
+                [&](u32 n, u32 i) -> u32 { return s_states[8u * n + i]; });
+            HSW_STAMP(4);
+            return;
+        }
+    }
+
+    const size_t blk = blockIdx.x / SMALL_ROLES;
+    const u32 role = blockIdx.x % SMALL_ROLES;
+    const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
+    u32 ps[8];                                   // this block's pre-state (wave-uniform)
+    if (p.flags & HSW_K_CHAINED) {
+        // ONE message: pre_states holds its initial state only; block b's pre-state is b compressions away
+        // (the roles that never look at the state skip the walk)
+#pragma unroll
+        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[i];
+        const bool needs_state = role < SMALL_ROUND_ROLES || role == SMALL_ROLE_FEED || role == SMALL_ROLE_STATE;
+        if (needs_state && blk != 0) {
+            // the message schedules of the blocks before this one do not depend on the state: lane l expands
+            // block l's (all at once), K + W goes through LDS (the tile is not in use yet; rows 65 words apart:
+            // no bank conflicts), and only the 64-round recurrence of each block remains serial
+            u32 *s_kw = reinterpret_cast<u32 *>(s_tile);
+            static_assert(sizeof(s_tile) >= 32 * 65 * 4, "K + W of 31 blocks must fit the tile");
+            if (lane < (u32)blk) {
+                const u32 *bl = reinterpret_cast<const u32 *>(p.blocks + 64 * (size_t)lane);
+                u32 w[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(bl[j]);
+#pragma unroll
+                for (int t = 0; t < 64; t++) {
+                    if (t >= 16)
+                        w[t & 15] = w[t & 15] + sha_s0(w[(t + 1) & 15]) + w[(t + 9) & 15] + sha_s1(w[(t + 14) & 15]);
+                    s_kw[lane * 65u + (u32)t] = w[t & 15] + K256[t];
+                }
+            }
+            __syncthreads();
+            for (u32 b = 0; b < (u32)blk; b++) {
+                u32 a = ps[0], bb = ps[1], c = ps[2], d = ps[3], e = ps[4], f = ps[5], g = ps[6], h = ps[7];
+                const u32 *kw = s_kw + b * 65u;
+#pragma unroll 16
+                for (int t = 0; t < 64; t++) {
+                    const u32 t1 = h + kw[t] + sha_S1(e) + sha_ch(e, f, g);
+                    const u32 t2 = sha_S0(a) + sha_maj(a, bb, c);
+                    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                }
+                ps[0] += a; ps[1] += bb; ps[2] += c; ps[3] += d; ps[4] += e; ps[5] += f; ps[6] += g; ps[7] += h;
+            }
+            __syncthreads();                       // the tile takes the memory over
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) ps[i] = p.pre_states[8 * blk + i];
+    }
+
+    // Montgomery launches: wave 0 of the workgroup emits, the others only take their share of every flush
+    // (Em::HELPERS; the same role program instantiated without the staging stores)
+    if constexpr (EM::HELPERS) {
+        using EMH = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true, false>;
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0)
+            small_role<L, REPR, RC, EMH>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
+        else
+            small_role<L, REPR, RC, EM>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
+    } else {
+        small_role<L, REPR, RC, EM>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
+    }
     HSW_STAMP(4);
 }
 
-// p.parts is ignored (37 waves per block, fixed); fr == nullptr: no frame waves.
+// 37 workgroups per block, of p.parts waves in Montgomery form (helper waves; p.parts is ignored otherwise);
+// fr == nullptr: no frame waves.
 template <int L>
 hipError_t launch_small_L(const ExpandParams &p, const SmallFrames *fr, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
+    const unsigned helpers = (p.flags & HSW_K_MONTGOMERY) ? p.parts : 1u;
+    if (helpers == 0 || helpers > (unsigned)HSW_SMALL_MAX_HELPERS) return hipErrorInvalidValue;
     SmallFrames f{};
     if (fr) f = *fr;
     const bool rc = (p.flags & HSW_K_INTERNALS) != 0u;
     if (f.n_frames && (!rc || (p.flags & HSW_K_COMPACT))) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(p.n_blocks * SMALL_ROLES + (size_t)f.n_frames * (f.state_waves + f.byte_waves))), block(64);
+    const dim3 grid((unsigned)(p.n_blocks * SMALL_ROLES + (size_t)f.n_frames * (f.state_waves + f.byte_waves))), block(64 * helpers);
     if (rc) {
         if (p.flags & HSW_K_MONTGOMERY) hipLaunchKernelGGL((hsw_small_kernel<L, 1, true>), grid, block, 0, stream, p, f);
         else if (p.flags & HSW_K_COMPACT) hipLaunchKernelGGL((hsw_small_kernel<L, 2, true>), grid, block, 0, stream, p, f);

@@ -160,6 +160,44 @@ def test_one_launch_whole_digest_equals_two_launches(hsw, oracle, mont):
             assert np.array_equal(got[0][k], got[1][k]), (sizes, k)
 
 
+@pytest.mark.parametrize("helpers", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("internals", [False, True])
+def test_montgomery_helper_waves(hsw, oracle, helpers, internals):
+    """Montgomery cells: "helpers" waves per workgroup (= role) share the conversions of every flush and scatter (a launch
+    this small is paced by one wave's instruction count).  Any helper count gives the cells of the plain
+    kernel, and of the oracle."""
+    N = hsw._native
+    mode = N.HSW_MODE_HALO2_INTERNALS if internals else N.HSW_MODE_DEFAULT
+    eng = hsw.WitnessEngine(0, 8, 3, mode=mode)
+    eng.set_option("helpers", helpers)
+    n = 18
+    blocks, pre = _inputs(n, 8100 + helpers)
+    blocks[0] = 0
+    pre[0] = 0
+    blocks[1] = 0xFF
+    pre[1] = 0xFFFFFFFF
+    import torch
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+
+    def run():
+        out = eng.witness_blocks_ex(tb, tp, cursor0=4, flags=N.HSW_REPR_MONTGOMERY, want_lookup=internals)
+        eng.synchronize()
+        return {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+
+    got = run()
+    li = eng.last_launch()
+    h = helpers if helpers else 4
+    assert li["split"] == 2 and li["parts"] == 37 * h and li["grid"] == 37 * n
+    eng.set_option("split", 0)
+    ref = run()
+    assert eng.last_launch()["split"] == 0
+    for k in ("gate", "dense", "spread", "next_states") + (("lookup",) if internals else ()):
+        assert np.array_equal(got[k], ref[k]), k
+    o = oracle.Oracle(8, 3, check=False, internals=internals).witness_blocks(blocks[:2], pre[:2], cursor0=4)
+    assert np.array_equal(got["gate"].view(np.uint64)[: 2 * eng.G], oracle.to_montgomery(o["gate"]))
+    eng.close()
+
+
 @pytest.mark.parametrize("nblk,flags_name", [(1, "canonical"), (16, "canonical"), (16, "montgomery"), (32, "canonical")])
 def test_chained_single_launch(hsw, oracle, nblk, flags_name):
     """HSW_CHAINED: the blocks are ONE message and d_pre_states holds its initial state only -- every wave

@@ -41,9 +41,13 @@ int main(int argc, char **argv) {
     }
     struct Cfg { const char *name; unsigned parts; unsigned flags; int tile; };
     const Cfg cfgs[] = {{"small-batch kernel (37 waves/block, one sub-unit program each)", 37, 0, -1},
+                        {"small-batch kernel, Montgomery cells, 1 wave per role", 1, hsw::HSW_K_MONTGOMERY, -1},
+                        {"small-batch kernel, Montgomery cells, 2 waves per role", 2, hsw::HSW_K_MONTGOMERY, -1},
+                        {"small-batch kernel, Montgomery cells, 4 waves per role", 4, hsw::HSW_K_MONTGOMERY, -1},
                         {"split (32 waves/block, one phase each)", 32, hsw::HSW_K_SPLIT, 32},
                         {"16 waves/block", 16, 0, 64}, {"4 waves/block", 4, 0, 64}};
     for (const Cfg &c : cfgs) {
+        if (c.tile < 0 && (c.flags & hsw::HSW_K_MONTGOMERY) && c.parts > HSW_SMALL_MAX_HELPERS) continue;
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = d_gate; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
@@ -58,7 +62,8 @@ int main(int argc, char **argv) {
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1)); float m; CK(hipEventElapsedTime(&m, e0, e1)); ms.push_back(m);
         }
-        const size_t waves = NB * c.parts;
+        const unsigned wpb = c.tile < 0 ? 37u : c.parts;       // workgroups per block (wave 0 of each stamps)
+        const size_t waves = NB * wpb;
         std::vector<unsigned long long> st(waves * 16);
         CK(hipMemcpy(st.data(), d_st, waves * 16 * 8, hipMemcpyDeviceToHost));
         std::sort(ms.begin(), ms.end());
@@ -75,14 +80,16 @@ int main(int argc, char **argv) {
         // per-wave durations of the split-mode programs of block 0
         if ((c.flags & hsw::HSW_K_SPLIT) || c.tile < 0) {
             printf("   block 0, per wave: chain / seeds / program (us)\n   ");
-            for (unsigned w = 0; w < c.parts; w++)
+            for (unsigned w = 0; w < wpb; w++)
                 printf("[%u] %.1f/%.1f/%.1f  ", w, (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 2] - st[w * 16 + 1]) * 0.01,
                        (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01);
             printf("\n");
         }
     }
+    for (int mont = 0; mont < 2; mont++)
     {   // whole-digest launch: one digest of NB blocks (1,024-byte class), frames in the same grid, 9-column breaks
         using LYR = hsw::Lay<2, true>;
+        const unsigned SW = (unsigned)std::min<size_t>(16, (192 + 76 * (NB + 1) + 352 + 127) / 128);
         const size_t GR = LYR::GATE_CELLS, PL = hsw::frame::prologue_cells(64 * NB, true), EL = hsw::frame::epilogue_cells(NB);
         const size_t cells = PL + 1 + NB * GR + EL, rows = 131063;
         void *d_gate2, *d_lk; unsigned long long *d_inv;
@@ -91,11 +98,11 @@ int main(int argc, char **argv) {
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = (char *)d_gate2 + (PL + 1) * 32; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
-        p.flags = hsw::HSW_K_INTERNALS; p.parts = 37;
+        p.flags = hsw::HSW_K_INTERNALS | (mont ? hsw::HSW_K_MONTGOMERY : 0u); p.parts = mont ? 4 : 37;
         p.lookup = (char *)d_lk + (3 + 2 * 64 * NB) * 32;
         p.frame_every = NB; p.frame_cells = PL + EL; p.frame_lookups = 3 + 2 * 64 * NB + 64;
         hsw::SmallFrames fr{};
-        fr.n_frames = 1; fr.state_waves = 4; fr.byte_waves = (unsigned)NB; fr.blocks0 = d_blocks; fr.pre0 = d_pre;
+        fr.n_frames = 1; fr.state_waves = SW; fr.byte_waves = (unsigned)NB; fr.blocks0 = d_blocks; fr.pre0 = d_pre;
         fr.gate0 = d_gate2; fr.lookup0 = d_lk; fr.inv_tbl = (const uint64_t *)d_inv;
         for (int k = 0; k < 16; k++) fr.brk.cell[k] = ~0ull;
         // column breaks every ~131,063 cells (relative to the block streams for the expansion, absolute for the frames)
@@ -109,7 +116,7 @@ int main(int argc, char **argv) {
         fr.d0.prologue_lookup = 0; fr.d0.epilogue_lookup = 3 + 2 * 64 * NB + NB * LYR::LOOKUP_CELLS; fr.d0.zero_cell = PL;
         fr.d0.n_blocks = (unsigned)NB; fr.d0.num_round = 2; fr.d0.precomputed_round = 0; fr.d0.range_check_inputs = 1;
         std::vector<float> ms;
-        const size_t waves = NB * 37 + 4 + NB;
+        const size_t waves = NB * 37 + SW + NB;
         for (int i = 0; i < 12; i++) {
             CK(hipMemset(d_st, 0, (NB * 64) * 16 * 8));
             CK(hipDeviceSynchronize());
@@ -123,7 +130,7 @@ int main(int argc, char **argv) {
         std::sort(ms.begin(), ms.end());
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < waves; w++) t0 = std::min(t0, st[w * 16]);
-        printf("whole digest, %zu blocks + frames in one launch (%u breaks): kernel (events) median %.1f us min %.1f us\n", NB, nb, ms[6] * 1e3, ms[0] * 1e3);
+        printf("whole digest%s, %zu blocks + frames in one launch (%u breaks): kernel (events) median %.1f us min %.1f us\n", mont ? " (Montgomery cells, 4 waves per role)" : "", NB, nb, ms[6] * 1e3, ms[0] * 1e3);
         double mx = 0;
         for (size_t w = 0; w < NB * 37; w++) mx = std::max(mx, (st[w * 16 + 4] - t0) * 0.01);
         printf("   block 0, per wave: chain / seeds / program (us)\n   ");
@@ -149,10 +156,10 @@ int main(int argc, char **argv) {
             }
         }
         printf("\n   expansion waves: last exit %.2f us\n   state waves (entry / chain+states done / exit): ", mx);
-        for (size_t w = NB * 37; w < NB * 37 + 4; w++)
+        for (size_t w = NB * 37; w < NB * 37 + SW; w++)
             printf("[%.1f %.1f %.1f] ", (st[w * 16] - t0) * 0.01, (st[w * 16 + 1] - t0) * 0.01, (st[w * 16 + 4] - t0) * 0.01);
         printf("\n   byte waves (entry / exit): ");
-        for (size_t w = NB * 37 + 4; w < waves; w++) printf("[%.1f %.1f] ", (st[w * 16] - t0) * 0.01, (st[w * 16 + 4] - t0) * 0.01);
+        for (size_t w = NB * 37 + SW; w < waves; w++) printf("[%.1f %.1f] ", (st[w * 16] - t0) * 0.01, (st[w * 16 + 4] - t0) * 0.01);
         printf("\n");
     }
     return 0;

@@ -17,16 +17,18 @@ static double now_us(void) {
 }
 static int cmp(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
 
-static void run(int whole, size_t max_size, size_t msg_len, int split, unsigned k) {
+static void run(int whole, size_t max_size, size_t msg_len, int split, unsigned k, int mont, int helpers) {
     hsw_engine *eng = NULL;
     if (hsw_engine_create_ex(0, NULL, 8, 2, whole ? HSW_MODE_HALO2_INTERNALS : HSW_MODE_DEFAULT, &eng) != HSW_OK) exit(1);
     hsw_engine_set_option(eng, "split", split);
+    hsw_engine_set_option(eng, "helpers", helpers);
     size_t sizes[64];
     for (int i = 0; i < 64; i++) sizes[i] = max_size;
     hsw_gadget *g = NULL;
     if (hsw_gadget_create_ex(eng, sizes, whole ? 1 : 64, 1, whole ? HSW_GADGET_WHOLE_DIGEST : 0, &g) != HSW_OK) exit(2);
     uint64_t columns = 0;
     if (whole && hsw_gadget_set_columns(g, (1u << k) - 9, &columns) != HSW_OK) exit(3);
+    if (mont && hsw_gadget_set_repr(g, HSW_REPR_MONTGOMERY) != HSW_OK) exit(6);
     uint8_t *msg = malloc(msg_len + 1);
     memset(msg, 1, msg_len);
     hsw_hash_result r;
@@ -44,8 +46,8 @@ static void run(int whole, size_t max_size, size_t msg_len, int split, unsigned 
     qsort(tr, N, sizeof(double), cmp);
     hsw_launch_info li;
     hsw_last_launch(eng, &li);
-    printf("%-13s max %5zu B (%2zu blocks) split=%2d -> kernel split %u, grid %llu: digest median %6.1f us  min %6.1f us  p90 %6.1f us | reset median %4.1f us\n",
-           whole ? "whole region" : "block streams", max_size, max_size / 64, split, li.split, (unsigned long long)li.grid,
+    printf("%-13s %s max %5zu B (%2zu blocks) split=%2d helpers=%d -> kernel split %u, grid %llu: digest median %6.1f us  min %6.1f us  p90 %6.1f us | reset median %4.1f us\n",
+           whole ? "whole region" : "block streams", mont ? "Montgomery" : "canonical ", max_size, max_size / 64, split, helpers, li.split, (unsigned long long)li.grid,
            td[N / 2], td[0], td[N * 9 / 10], tr[N / 2]);
     free(msg);
     hsw_gadget_destroy(g);
@@ -53,13 +55,21 @@ static void run(int whole, size_t max_size, size_t msg_len, int split, unsigned 
 }
 
 int main(void) {
-    run(1, 1024, 56, -1, 17);
-    run(1, 1024, 56, 0, 17);
-    run(0, 1024, 56, -1, 17);
-    run(0, 1024, 56, 0, 17);
-    run(1, 128, 3, -1, 17);
-    run(1, 2048, 2000, -1, 18);
-    run(1, 2048, 2000, 0, 18);
-    run(0, 64, 3, -1, 17);
+    run(1, 1024, 56, -1, 17, 0, 0);
+    run(1, 1024, 56, 0, 17, 0, 0);
+    run(0, 1024, 56, -1, 17, 0, 0);
+    run(0, 1024, 56, 0, 17, 0, 0);
+    run(1, 128, 3, -1, 17, 0, 0);
+    run(1, 2048, 2000, -1, 18, 0, 0);
+    run(1, 2048, 2000, 0, 18, 0, 0);
+    run(0, 64, 3, -1, 17, 0, 0);
+    run(1, 1024, 56, -1, 17, 1, 0);
+    run(1, 1024, 56, 0, 17, 1, 0);
+    run(0, 1024, 56, -1, 17, 1, 0);
+    run(1, 2048, 2000, -1, 18, 1, 0);
+    for (int h = 1; h <= 4; h *= 2) run(1, 1024, 56, -1, 17, 1, h);
+    for (int h = 1; h <= 4; h *= 2) run(1, 2048, 2000, -1, 18, 1, h);
+    run(1, 128, 3, -1, 17, 1, 0);
+    run(1, 128, 3, -1, 17, 1, 1);
     return 0;
 }
