@@ -464,8 +464,10 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             }
         }
         if (small) {
-            // Montgomery cells: helper waves share each role's conversions (hsw_expand.hpp Em::HELPERS)
-            const uint32_t helpers = !(flags & HSW_REPR_MONTGOMERY) ? 1u : e->helpers ? (uint32_t)e->helpers : 4u;
+            // waves per workgroup: they share every flush (hsw_expand.hpp Em::HELPERS)
+            // (measured, tools/region_latency.c sweep: 4 is best up to 16 blocks and always for the Montgomery
+            //  conversion; the plain write-out of more blocks than that has enough waves with 2)
+            const uint32_t helpers = e->helpers ? (uint32_t)e->helpers : ((flags & HSW_REPR_MONTGOMERY) || n <= 16) ? 4u : 2u;
             p.parts = helpers;
             p.next_states_host = host_next_states ? host_next_states + 8 * done : nullptr;
             he = hsw::launch_small(p, done == 0 ? frames : nullptr, e->limbs, e->stream);

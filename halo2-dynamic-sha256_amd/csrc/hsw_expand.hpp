@@ -218,15 +218,19 @@ struct Em {
     //  tails and heads are not neighbours in the stream.)
     static constexpr bool REALIGN = !NO_REALIGN_ && (REPR_ == 0 || (REPR_ == 1 && RC_));
     static constexpr int STRIDE = REALIGN ? T + 3 : T + 1;   // u64 per tile row: T cells + up to 3 carried ones (odd: no bank conflicts)
-    // Helper waves (small-batch kernel, Montgomery cells): the workgroup is hcnt waves sharing one tile; each
-    // converts and stores every hcnt-th 64-cell run of a flush -- the conversion is two thirds of a wave's
-    // instructions in a launch paced by exactly that.  hsel = this wave's index.  Wave 0 is the emitter; the
-    // others run the same program instantiated with EMITS = false: nothing is staged, so the compiler drops
-    // the arithmetic and what remains is the role's sequence of flushes (barrier, convert a share, barrier).
-    // (Helper waves as extra workgroups were slower beyond 2: workgroup dispatch, ~5 ns each, paces the launch;
-    //  helpers that repeat the emission, 27 vs 32 us per 16 blocks: the VALUs of 592 workgroups are the bound.)
+    // Helper waves (small-batch kernel): the workgroup is hcnt waves sharing one tile.  Wave 0 is the emitter;
+    // the others run the same role program instantiated with EMITS = false -- nothing is staged, so the
+    // compiler drops the arithmetic and what remains is the role's sequence of flushes.  At a flush every wave,
+    // the emitter included, takes every hcnt-th row / 64-cell run: a launch this small is paced by one wave's
+    // instruction count, and the write-out is most of it (two thirds in canonical form, more in Montgomery
+    // form).  hsel = this wave's index (wave-uniform: the flush loops stay scalar).
+    // Measured and dropped: helper waves as extra workgroups (slower beyond 2: workgroup dispatch, ~5 ns each,
+    // paces the launch); helpers that repeat the emission (27 vs 32 us per 16 Montgomery blocks: the VALUs of
+    // 592 workgroups are the bound); double-buffered tiles with a dedicated emitter wave (the emission is the
+    // smaller part, so a wave that only emits is a flusher lost: 25.0 vs 22.8 us); a launch bound of 512
+    // threads (every wave of the kernel crawled, 57 vs 33 us).
+    static constexpr bool HELPERS = NO_REALIGN_;
     static constexpr bool EMITS = EMITS_;
-    static constexpr bool HELPERS = NO_REALIGN_ && REPR_ == 1;
     u32 hsel, hcnt;
     u64 *row0;         // this lane's tile row (LDS), column 0
     u32 skew;          // 0..3, wave-uniform: cells by which this phase's units start past a 128-byte line
@@ -308,6 +312,10 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
     const u32 lane = lane_id();
     char *base = reinterpret_cast<char *>(em.out);
     const u32 skew = EM::REALIGN ? em.skew : 0u;
+    // helper waves (Em::HELPERS): wave hs of hn takes rows / 64-cell runs hs, hs + hn, ...
+    const u64 *tile = em.tile;
+    u32 hs = 0, hn = 1;
+    if constexpr (EM::HELPERS) { hs = em.hsel; hn = em.hcnt; }
     // FlexGate column breaks inside this block (wave-uniform; none unless a pack plan is in force): a flush
     // whose cells all lie on one side of them is only SHIFTED by the gaps it has passed and keeps the fast
     // paths; only a flush that straddles a break places every piece on its own (`packed`).
@@ -377,14 +385,13 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
         if (plain_partial) {
             const u32 row_bytes = em.unit_cells * (EM::COMPACT ? 8u : 32u);
             if constexpr (EM::COMPACT) {
-                const u64 *src = em.tile + lane;
-                u32 cl0 = em.cell_base + seg + lane;
-                for (u32 r = 0; r < em.nrows; r++, src += S, cl0 += em.unit_cells)
+                const u64 *src = tile + lane + hs * S;
+                u32 cl0 = em.cell_base + seg + lane + hs * em.unit_cells;
+                for (u32 r = hs; r < em.nrows; r += hn, src += hn * S, cl0 += hn * em.unit_cells)
                     for (u32 q = 0; lane + q < ncells; q += 64)
                         store8(base, (packed ? packed_cell(em, cl0 + q) : cl0 + q + shift) * 8u, src[q]);
             } else if constexpr (EM::MONT) {
-                const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;    // rows dealt to the helper waves
-                const u64 *src = em.tile + lane + hs * S;
+                const u64 *src = tile + lane + hs * S;
                 u32 cl0 = em.cell_base + seg + lane + hs * em.unit_cells;
                 for (u32 r = hs; r < em.nrows; r += hn, src += hn * S, cl0 += hn * em.unit_cells)
                     for (u32 q = 0; lane + q < ncells; q += 64) {
@@ -401,10 +408,10 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                 // like the full-tile path below: all T / 32 LDS reads of a row first (columns past ncells hold
                 // stale cells of the same row -- read, never stored), then the stores
                 const u32 h = lane & 1u, p0 = lane >> 1;
-                const u64 *src = em.tile + p0;
+                const u64 *src = tile + p0 + hs * S;
                 const u32 cell0 = em.cell_base + seg + p0;
-                u32 off = ((cell0 + shift) * 2u + h) * 16u;
-                for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+                u32 off = ((cell0 + shift) * 2u + h) * 16u + hs * row_bytes;
+                for (u32 r = hs; r < em.nrows; r += hn, src += hn * S, off += hn * row_bytes) {
                     bool strad = false;
                     u32 offr = off;
                     if (packed) offr = ((cell0 + r * em.unit_cells + row_shift(r, strad)) * 2u + h) * 16u;
@@ -431,23 +438,22 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
             // 8-byte cells: one lane per cell, 512 B contiguous per wave-instruction.
             // Negation cells keep x (their positions are static: hsw_neg_cells).  (skew is always 0 here)
 #pragma unroll 4
-            for (u32 i = lane; i < total_cells; i += 64) {
+            for (u32 i = lane + 64u * hs; i < total_cells; i += 64u * hn) {
                 const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = lo0 + i - r * ncols;
                 u32 cl = cell_sh + r * em.unit_cells + p;
                 if (packed) cl = packed_cell(em, cl);
-                store8(base, cl * 8u, em.tile[r * S + p]);
+                store8(base, cl * 8u, tile[r * S + p]);
             }
         } else if constexpr (EM::MONT) {
             // full tiles index by the compile-time T (a shift) and skip the < 4 empty / held-back columns
             // of a skewed unit's first tile; partial ones divide by the run length
             const u32 total = FULL ? em.nrows * (u32)T : total_cells;
-            const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;        // 64-cell runs dealt to the helper waves
             for (u32 i = lane + 64u * hs; i < total; i += 64u * hn) {
                 const u32 r = FULL ? i / (u32)T : row_of(i, 1u);
                 const u32 p = FULL ? i % (u32)T : lo0 + i - r * ncols;
                 if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
-                const u64 v = em.tile[r * S + p];
+                const u64 v = tile[r * S + p];
                 Fe8 m = mont_cell<EM>(v);
                 if (any_neg) {                        // compile-time false for most tiles
                     if (is_neg(p) && v != 0ull) m = fe_neg_nonzero(m);
@@ -462,11 +468,11 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
             // (l >> 1) + 32 k of every row; LDS and HBM addresses advance by constants (a row next to a
             // column break is re-based, one that straddles it placed piece by piece).
             const u32 h = lane & 1u, p0 = lane >> 1;
-            const u64 *src = em.tile + p0;
-            const u32 cell0 = em.cell_base + seg + p0;
-            u32 off = ((cell0 + shift) * 2u + h) * 16u;
             const u32 row_bytes = em.unit_cells * 32u;
-            for (u32 r = 0; r < em.nrows; r++, src += S, off += row_bytes) {
+            const u64 *src = tile + p0 + hs * S;
+            const u32 cell0 = em.cell_base + seg + p0;
+            u32 off = ((cell0 + shift) * 2u + h) * 16u + hs * row_bytes;
+            for (u32 r = hs; r < em.nrows; r += hn, src += hn * S, off += hn * row_bytes) {
                 const bool skip0 = first_skewed && p0 < (r == 0u ? lo0 : lo);
                 bool strad = false;
                 u32 offr = off;
@@ -495,7 +501,7 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
                 const u32 q = i - r * ppr;
                 const u32 p = (FULL ? 0u : lo0) + (q >> 1), h = q & 1u;
                 if (first_skewed && p < (r == 0u ? lo0 : lo)) continue;
-                const u64 v = em.tile[r * S + p];
+                const u64 v = tile[r * S + p];
                 const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
                 uint4 o = make_uint4(h ? 0u : vlo, h ? 0u : vhi, 0u, 0u);
                 if (any_neg) {

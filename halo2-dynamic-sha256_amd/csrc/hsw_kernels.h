@@ -21,7 +21,7 @@ enum : uint32_t {
 enum { HSW_K_MAX_BREAKS = 16 };
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)
 #ifndef HSW_SMALL_MAX_HELPERS
-#define HSW_SMALL_MAX_HELPERS 4            // waves per role (workgroup) when it writes Montgomery cells; a launch
+#define HSW_SMALL_MAX_HELPERS 4            // waves per role (workgroup): the emitter + up to 3 helper waves; a launch
                                            // bound of 512 threads made every wave of the kernel crawl (57 vs 33 us)
 #endif
 

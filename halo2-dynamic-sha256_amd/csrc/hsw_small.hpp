@@ -139,7 +139,7 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
     const u32 c0 = (u32)(n0 - r0 * p.ncols), ncols = p.ncols;
     const size_t rbase = (size_t)(r0 - p.cursor0 / p.ncols);
     constexpr u32 CB = EM::COMPACT ? 8u : 32u;
-    const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;
+    const u32 hs = em.hsel, hn = em.hcnt;             // all waves of the workgroup, the emitter included
     for (u32 k = lane + 64u * hs; k < total; k += 64u * hn) {
         const u32 r = k / per_row, j = k - r * per_row;
         const u32 limb = ((u32)em.d16[r * sub_calls + j / (u32)L] >> (B * (j % (u32)L))) & MASK;
@@ -175,7 +175,7 @@ DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block
     __syncthreads();
     const u32 lane = lane_id();
     const u32 total = em.nrows * sub_lk;
-    const u32 hs = EM::HELPERS ? em.hsel : 0u, hn = EM::HELPERS ? em.hcnt : 1u;
+    const u32 hs = em.hsel, hn = em.hcnt;             // all waves of the workgroup, the emitter included
     for (u32 k = lane + 64u * hs; k < total; k += 64u * hn) {
         const u32 r = k / sub_lk, j = k - r * sub_lk;
         const u32 v = em.lk16[k];
@@ -221,8 +221,8 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
     em.carry_neg = 0;
     em.head = nullptr;
     em.d16 = s_d16;
-    em.hsel = EM::HELPERS ? threadIdx.x >> 6 : 0u;          // Montgomery launches: blockDim.x / 64 waves share the role
-    em.hcnt = EM::HELPERS ? blockDim.x >> 6 : 1u;
+    em.hsel = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (the flush loops stay scalar); blockDim.x / 64 waves share the role
+    em.hcnt = blockDim.x >> 6;
 
     {   // FlexGate column packing: gaps of the breaks at or before this block, and the (<= 2) inside it
         u64 first = (u64)blk * (u64)LY::GATE_CELLS;
@@ -398,7 +398,7 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
 }
 
 template <int L, int REPR, bool RC>
-__global__ __launch_bounds__(REPR == 1 ? 64 * HSW_SMALL_MAX_HELPERS : 64) void hsw_small_kernel(ExpandParams p, SmallFrames fr) {
+__global__ __launch_bounds__(64 * HSW_SMALL_MAX_HELPERS) void hsw_small_kernel(ExpandParams p, SmallFrames fr) {
     using SP = SmallPlan<L, RC>;
     using EM = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true>;
     __shared__ u64 s_tile[(SMALL_ROWS + 1) * EM::STRIDE];                   // +1 scratch row for lanes >= 16
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(REPR == 1 ? 64 * HSW_SMALL_MAX_HELPERS : 64) void h
     // ---- frame waves (whole-digest launches): hsw_frame_body.hpp ------------------------------------
     if constexpr (RC && REPR != 2) {
         if (blockIdx.x >= n_expand) {
-            if (EM::HELPERS && threadIdx.x >= 64u) return;       // (frame workgroups use their first wave only)
+            if (threadIdx.x >= 64u) return;                      // (frame workgroups use their first wave only)
             const u32 wpf = fr.state_waves + fr.byte_waves;
             const u32 fw = blockIdx.x - n_expand, fi = fw / wpf, slice = fw % wpf;
             const FrameDesc d = fi == 0u ? fr.d0 : fr.descs[fi];
@@ -496,26 +496,22 @@ __global__ __launch_bounds__(REPR == 1 ? 64 * HSW_SMALL_MAX_HELPERS : 64) void h
         for (int i = 0; i < 8; i++) ps[i] = p.pre_states[8 * blk + i];
     }
 
-    // Montgomery launches: wave 0 of the workgroup emits, the others only take their share of every flush
-    // (Em::HELPERS; the same role program instantiated without the staging stores)
-    if constexpr (EM::HELPERS) {
-        using EMH = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true, false>;
-        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0)
-            small_role<L, REPR, RC, EMH>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
-        else
-            small_role<L, REPR, RC, EM>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
-    } else {
+    // wave 0 of the workgroup emits, the others (if any) only take their share of every flush: the same role
+    // program instantiated without the staging stores (Em::HELPERS)
+    using EMH = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true, false>;
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0)
+        small_role<L, REPR, RC, EMH>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
+    else
         small_role<L, REPR, RC, EM>(p, bw, ps, blk, role, s_tile, s_d16, s_lk16);
-    }
     HSW_STAMP(4);
 }
 
-// 37 workgroups per block, of p.parts waves in Montgomery form (helper waves; p.parts is ignored otherwise);
+// 37 workgroups per block, of p.parts waves each (the emitter + p.parts - 1 helper waves, Em::HELPERS);
 // fr == nullptr: no frame waves.
 template <int L>
 hipError_t launch_small_L(const ExpandParams &p, const SmallFrames *fr, hipStream_t stream) {
     if (p.n_blocks == 0) return hipSuccess;
-    const unsigned helpers = (p.flags & HSW_K_MONTGOMERY) ? p.parts : 1u;
+    const unsigned helpers = p.parts;
     if (helpers == 0 || helpers > (unsigned)HSW_SMALL_MAX_HELPERS) return hipErrorInvalidValue;
     SmallFrames f{};
     if (fr) f = *fr;

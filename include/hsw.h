@@ -629,8 +629,9 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
  * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": how tiny batches
  * are dealt to waves -- -1 = the small-batch kernel (37 waves per block, one sub-unit program each) for
  * batches of <= 32 blocks (default), 0 = never, 1 = one phase program per wave (32 waves per block),
- * 2 = the small-batch kernel always.  "helpers": waves per workgroup (= role) of the small-batch kernel when
- * it writes Montgomery cells (they share the conversions), 0 = default (4), 1..4.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
+ * 2 = the small-batch kernel always.  "helpers": waves per workgroup (= role) of the small-batch kernel --
+ * they share the write-out of every tile; 0 = chosen by the engine (default: 4, or 2 for more than 16 blocks
+ * of canonical / compact cells), 1..4.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
  * "chunk_blocks": blocks per kernel launch of a long batch (default and maximum 2^20; a test knob). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 

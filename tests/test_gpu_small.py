@@ -162,11 +162,14 @@ def test_one_launch_whole_digest_equals_two_launches(hsw, oracle, mont):
 
 @pytest.mark.parametrize("helpers", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("internals", [False, True])
-def test_montgomery_helper_waves(hsw, oracle, helpers, internals):
-    """Montgomery cells: "helpers" waves per workgroup (= role) share the conversions of every flush and scatter (a launch
-    this small is paced by one wave's instruction count).  Any helper count gives the cells of the plain
-    kernel, and of the oracle."""
+@pytest.mark.parametrize("flags_name", ["canonical", "montgomery", "compact"])
+def test_helper_waves(hsw, oracle, helpers, internals, flags_name):
+    """A workgroup of the small-batch kernel is "helpers" waves (default 4, or 2 for more than 16 blocks of canonical / compact cells): wave 0 emits, and all of them share
+    the conversion and write-out of every tile.  Any count gives the cells of the streaming kernel, and of
+    the oracle."""
+    import torch
     N = hsw._native
+    flags = {"canonical": 0, "montgomery": N.HSW_REPR_MONTGOMERY, "compact": N.HSW_REPR_COMPACT64}[flags_name]
     mode = N.HSW_MODE_HALO2_INTERNALS if internals else N.HSW_MODE_DEFAULT
     eng = hsw.WitnessEngine(0, 8, 3, mode=mode)
     eng.set_option("helpers", helpers)
@@ -176,25 +179,26 @@ def test_montgomery_helper_waves(hsw, oracle, helpers, internals):
     pre[0] = 0
     blocks[1] = 0xFF
     pre[1] = 0xFFFFFFFF
-    import torch
     tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
 
     def run():
-        out = eng.witness_blocks_ex(tb, tp, cursor0=4, flags=N.HSW_REPR_MONTGOMERY, want_lookup=internals)
+        out = eng.witness_blocks_ex(tb, tp, cursor0=4, flags=flags, want_lookup=internals)
         eng.synchronize()
         return {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
 
     got = run()
     li = eng.last_launch()
-    h = helpers if helpers else 4
+    h = helpers if helpers else (4 if flags_name == "montgomery" else 2)      # 18 blocks: 2 unless Montgomery
     assert li["split"] == 2 and li["parts"] == 37 * h and li["grid"] == 37 * n
     eng.set_option("split", 0)
     ref = run()
     assert eng.last_launch()["split"] == 0
     for k in ("gate", "dense", "spread", "next_states") + (("lookup",) if internals else ()):
         assert np.array_equal(got[k], ref[k]), k
-    o = oracle.Oracle(8, 3, check=False, internals=internals).witness_blocks(blocks[:2], pre[:2], cursor0=4)
-    assert np.array_equal(got["gate"].view(np.uint64)[: 2 * eng.G], oracle.to_montgomery(o["gate"]))
+    if flags_name != "compact":
+        o = oracle.Oracle(8, 3, check=False, internals=internals).witness_blocks(blocks[:2], pre[:2], cursor0=4)
+        exp = oracle.to_montgomery(o["gate"]) if flags_name == "montgomery" else o["gate"]
+        assert np.array_equal(got["gate"].view(np.uint64)[: 2 * eng.G], exp)
     eng.close()
 
 

@@ -40,14 +40,17 @@ int main(int argc, char **argv) {
         printf("empty kernel (512 waves) between two events: median %.1f us, min %.1f us\n", ms[10] * 1e3, ms[0] * 1e3);
     }
     struct Cfg { const char *name; unsigned parts; unsigned flags; int tile; };
-    const Cfg cfgs[] = {{"small-batch kernel (37 waves/block, one sub-unit program each)", 37, 0, -1},
+    const Cfg cfgs[] = {{"small-batch kernel (37 roles/block), 1 wave per role", 1, 0, -1},
+                        {"small-batch kernel, 2 waves per role", 2, 0, -1},
+                        {"small-batch kernel, 3 waves per role", 3, 0, -1},
+                        {"small-batch kernel, 4 waves per role", 4, 0, -1},
                         {"small-batch kernel, Montgomery cells, 1 wave per role", 1, hsw::HSW_K_MONTGOMERY, -1},
                         {"small-batch kernel, Montgomery cells, 2 waves per role", 2, hsw::HSW_K_MONTGOMERY, -1},
                         {"small-batch kernel, Montgomery cells, 4 waves per role", 4, hsw::HSW_K_MONTGOMERY, -1},
                         {"split (32 waves/block, one phase each)", 32, hsw::HSW_K_SPLIT, 32},
                         {"16 waves/block", 16, 0, 64}, {"4 waves/block", 4, 0, 64}};
     for (const Cfg &c : cfgs) {
-        if (c.tile < 0 && (c.flags & hsw::HSW_K_MONTGOMERY) && c.parts > HSW_SMALL_MAX_HELPERS) continue;
+        if (c.tile < 0 && c.parts > HSW_SMALL_MAX_HELPERS) continue;
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = d_gate; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
@@ -98,7 +101,7 @@ int main(int argc, char **argv) {
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = (char *)d_gate2 + (PL + 1) * 32; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
-        p.flags = hsw::HSW_K_INTERNALS | (mont ? hsw::HSW_K_MONTGOMERY : 0u); p.parts = mont ? 4 : 37;
+        p.flags = hsw::HSW_K_INTERNALS | (mont ? hsw::HSW_K_MONTGOMERY : 0u); p.parts = 4;
         p.lookup = (char *)d_lk + (3 + 2 * 64 * NB) * 32;
         p.frame_every = NB; p.frame_cells = PL + EL; p.frame_lookups = 3 + 2 * 64 * NB + 64;
         hsw::SmallFrames fr{};
@@ -130,7 +133,7 @@ int main(int argc, char **argv) {
         std::sort(ms.begin(), ms.end());
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < waves; w++) t0 = std::min(t0, st[w * 16]);
-        printf("whole digest%s, %zu blocks + frames in one launch (%u breaks): kernel (events) median %.1f us min %.1f us\n", mont ? " (Montgomery cells, 4 waves per role)" : "", NB, nb, ms[6] * 1e3, ms[0] * 1e3);
+        printf("whole digest%s, %zu blocks + frames in one launch (%u breaks): kernel (events) median %.1f us min %.1f us\n", mont ? " (Montgomery cells, 4 waves per role)" : " (4 waves per role)", NB, nb, ms[6] * 1e3, ms[0] * 1e3);
         double mx = 0;
         for (size_t w = 0; w < NB * 37; w++) mx = std::max(mx, (st[w * 16 + 4] - t0) * 0.01);
         printf("   block 0, per wave: chain / seeds / program (us)\n   ");
