@@ -523,6 +523,35 @@ def extra_config0(hsw, local_rank, with_cpu):
     else:
         res["whole_region_to_host_compact"] = {"error": n_wide}
     cfgw.close()
+    # the same region in Montgomery form -- what bn256::Fr holds in memory, so what the Rust shim
+    # (rust/reference-patch/src/hsw.rs) hands to region.assign_advice without a conversion per cell
+    try:
+        cfgm = hsw.Sha256DynamicConfig(eng_i, [1024], True, whole_digest=True)
+        cfgm.set_repr(hsw._native.HSW_REPR_MONTGOMERY)
+        cfgm.set_columns((1 << 17) - 9)
+        for _ in range(6):
+            assert L.hsw_gadget_reset(cfgm.h) == 0 and L.hsw_gadget_digest(cfgm.h, mbuf, 56, 0, C.byref(hres)) == 0
+        tm = []
+        for _ in range(200):
+            assert L.hsw_gadget_reset(cfgm.h) == 0
+            t1 = time.perf_counter()
+            rcm = L.hsw_gadget_digest(cfgm.h, mbuf, 56, 0, C.byref(hres))
+            tm.append(time.perf_counter() - t1)
+            assert rcm == 0
+        assert bytes(hres.output_bytes) == hashlib.sha256(m56).digest()
+        lm = eng_i.last_launch()
+        vm = cfgm.verify()
+        res["whole_region_montgomery"] = {
+            "ms_per_synthesis": float(np.median(tm)) * 1e3, "ms_min": float(np.min(tm)) * 1e3,
+            "ms_p90": float(np.percentile(tm, 90)) * 1e3, "blocks_per_s": 16 / float(np.median(tm)),
+            "GBps": region_bytes / float(np.median(tm)) / 1e9, "frac_of_peak": region_bytes / float(np.median(tm)) / 1e9 / HBM_PEAK_GBS,
+            "kernel": lm["kernel"], "waves_per_block": lm["parts"], "grid": lm["grid"],
+            "verify_on_device": {"violations": vm["violations"], "checks": vm["checks"]},
+            "note": "the same synthesis with cells in Montgomery form (x * 2^256 mod p, halo2curves' in-memory Fr): "
+                    "the form the Rust shim consumes"}
+        cfgm.close()
+    except Exception as ex:
+        res["whole_region_montgomery"] = {"error": repr(ex)}
     eng_i.close()
     if with_cpu:
         try:

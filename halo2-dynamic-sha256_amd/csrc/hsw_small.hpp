@@ -200,8 +200,11 @@ DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block
 template <int L, class EM, class C>
 DEV void sub_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base, u32 call0,
                  u32 calls_per_unit, u32 sub_calls, u32 lk0, u32 lk_per_unit, u32 sub_lk) {
+    HSW_STAMP(5);
     if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+    HSW_STAMP(6);
     scatter_chip<L>(em, p, block_first_limb, call0, calls_per_unit, sub_calls);
+    HSW_STAMP(7);
     if constexpr (EM::RC) scatter_lookup(em, p, lookup_block_base, lk0, lk_per_unit, sub_lk);
 }
 

@@ -81,6 +81,13 @@ int main(int argc, char **argv) {
             printf("   %-13s min %6.2f  median %6.2f  max %6.2f us\n", names[k], v.front(), v[v.size() / 2], v.back());
         }
         // per-wave durations of the split-mode programs of block 0
+        if (c.tile < 0) {
+            printf("   block 0, roles 0..32: emission+full flushes / last flush / chip scatter / rest (us)\n   ");
+            for (unsigned w = 0; w < 33; w++)
+                printf("[%u] %.1f/%.1f/%.1f/%.1f  ", w, (st[w * 16 + 5] - st[w * 16 + 2]) * 0.01, (st[w * 16 + 6] - st[w * 16 + 5]) * 0.01,
+                       (st[w * 16 + 7] - st[w * 16 + 6]) * 0.01, (st[w * 16 + 4] - st[w * 16 + 7]) * 0.01);
+            printf("\n");
+        }
         if ((c.flags & hsw::HSW_K_SPLIT) || c.tile < 0) {
             printf("   block 0, per wave: chain / seeds / program (us)\n   ");
             for (unsigned w = 0; w < wpb; w++)
