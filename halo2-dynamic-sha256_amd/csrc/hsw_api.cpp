@@ -337,7 +337,7 @@ int hsw_witness_blocks_ex(hsw_engine *e, const hsw_witness_args *args) try {
 bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks) {
     if (e->limbs != 2) return false;
     if (e->split == 2) return true;
-    return e->split < 0 && e->parts == 0 && e->tile == 0 && n_blocks <= 32;
+    return e->split < 0 && e->parts == 0 && e->tile == 0 && n_blocks <= (size_t)hsw::HSW_SMALL_AUTO_BLOCKS;
 }
 
 // hsw_witness_blocks_ex, plus (small-batch launches only) the digest frames written by waves of the same
@@ -355,7 +355,7 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
     if (n_blocks == 0) return HSW_OK;
     if (flags & ~(HSW_REPR_MASK | HSW_SKIP_GATE | HSW_SKIP_CHIP | HSW_CHAINED))
         return set_err(e, HSW_ERR_INVALID_ARG, "unknown flag bits");
-    if ((flags & HSW_CHAINED) && (!hsw_small_eligible(e, n_blocks) || n_blocks > e->chunk_blocks || frames))
+    if ((flags & HSW_CHAINED) && (!hsw_small_eligible(e, n_blocks) || n_blocks > 32 || n_blocks > e->chunk_blocks || frames))
         return set_err(e, HSW_ERR_UNSUPPORTED, "HSW_CHAINED: small-batch launches only (<= 32 blocks, 8-bit table); run hsw_sha256_chain first");
     if ((flags & HSW_REPR_MASK) == HSW_REPR_MASK)
         return set_err(e, HSW_ERR_INVALID_ARG, "HSW_REPR_MONTGOMERY and HSW_REPR_COMPACT64 are exclusive");
@@ -465,9 +465,10 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
         }
         if (small) {
             // waves per workgroup: they share every flush (hsw_expand.hpp Em::HELPERS)
-            // (measured, tools/region_latency.c sweep: 4 is best up to 16 blocks and always for the Montgomery
-            //  conversion; the plain write-out of more blocks than that has enough waves with 2)
-            const uint32_t helpers = e->helpers ? (uint32_t)e->helpers : ((flags & HSW_REPR_MONTGOMERY) || n <= 16) ? 4u : 2u;
+            // (measured, tools/region_latency.c sweep and tools/small_n.py: the Montgomery conversion always wants
+            //  4; the plain write-out 4 up to 16 blocks, 2 up to 64 and 1 beyond -- enough waves there already)
+            const uint32_t helpers = e->helpers ? (uint32_t)e->helpers
+                                     : ((flags & HSW_REPR_MONTGOMERY) || n <= 16) ? 4u : n <= 64 ? 2u : 1u;
             p.parts = helpers;
             p.next_states_host = host_next_states ? host_next_states + 8 * done : nullptr;
             he = hsw::launch_small(p, done == 0 ? frames : nullptr, e->limbs, e->stream);

@@ -432,15 +432,15 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     hsw_engine_stream(ctx.engine, reinterpret_cast<void **>(&stream), &device);
     DeviceScope ds(device);
     if (!ds.ok) return HSW_ERR_NO_DEVICE;
-    // Up to 32 blocks the expansion reads its 96 input bytes per block straight from the pinned staging
-    // (uncached PCIe reads: cheaper than two copies for a handful of waves, not beyond).
+    // Small-batch launches (and any launch of up to 32 blocks) read their 96 input bytes per block straight from
+    // the pinned staging (uncached PCIe reads: cheaper than two dependent copies while the waves are few).
     // Tiny batches (the reference's bench circuit is ONE 16-block digest) are latency-bound: they go to the
     // small-batch kernel, which for a whole-digest context also writes the frames -- ONE launch, inputs read
     // in place from the pinned staging, next states written straight into pinned memory, no copy launches.
     bool one_run = true;                       // whole-digest contexts: all digests of the batch equally sized
     for (size_t i = 1; i < n; i++) one_run = one_run && plans[i].max_variable_round == plans[0].max_variable_round;
     const bool small = hsw_small_eligible(ctx.engine, batch_blocks) && (!ctx.whole || one_run);
-    const bool zero_copy = host_chain && batch_blocks <= 32 && (!ctx.whole || small);
+    const bool zero_copy = host_chain && (ctx.whole ? small : (small || batch_blocks <= 32));
     const uint8_t *in_blocks = zero_copy ? ctx.dp_blocks : ctx.d_blocks;        // bases, indexed by absolute block
     const uint32_t *in_pre = zero_copy ? ctx.dp_pre : ctx.d_pre_states;
     const uint8_t *d_blk = in_blocks + 64 * b0;

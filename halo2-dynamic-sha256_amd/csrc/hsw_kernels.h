@@ -20,6 +20,8 @@ enum : uint32_t {
 };
 enum { HSW_K_MAX_BREAKS = 16 };
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)
+enum { HSW_SMALL_AUTO_BLOCKS = 128 };      // the engine picks the small-batch kernel up to this many blocks per launch
+                                           // (tools/small_n.py: faster than the streaming kernel up to ~190 canonical, ~250 Montgomery)
 #ifndef HSW_SMALL_MAX_HELPERS
 #define HSW_SMALL_MAX_HELPERS 4            // waves per role (workgroup): the emitter + up to 3 helper waves; a launch
                                            // bound of 512 threads made every wave of the kernel crawl (57 vs 33 us)

@@ -453,8 +453,8 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
                        void *d_lookup, const hsw_pack_plan *pack, uint32_t flags);
 
 /* Block streams AND frames of n equally sized digests in one call: what hsw_witness_blocks_ex (with
- * frame_every = the digests' block count) followed by hsw_witness_frames do.  For up to 32 blocks -- the
- * reference's own bench circuit is one 16-block digest -- it is ONE kernel launch: the frame cells are
+ * frame_every = the digests' block count) followed by hsw_witness_frames do.  For up to 128 blocks in digests of
+ * up to 32 -- the reference's own bench circuit is one 16-block digest -- it is ONE kernel launch: the frame cells are
  * written by extra waves of the expansion's grid, which take the candidate states from the chain inputs
  * (pre-state of block b + 1 = next state of block b) and compute the last block's output themselves, so
  * nothing waits for the expansion.  Larger batches: the two launches above.
@@ -628,10 +628,10 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
  * contiguous run of one unit, 0 = chosen by the engine (default), 32, 64 or 128
  * (also 6416 = [16 rows][64 cells], the default of the compact form).  "split": how tiny batches
  * are dealt to waves -- -1 = the small-batch kernel (37 waves per block, one sub-unit program each) for
- * batches of <= 32 blocks (default), 0 = never, 1 = one phase program per wave (32 waves per block),
+ * batches of <= 128 blocks (default), 0 = never, 1 = one phase program per wave (32 waves per block),
  * 2 = the small-batch kernel always.  "helpers": waves per workgroup (= role) of the small-batch kernel --
- * they share the write-out of every tile; 0 = chosen by the engine (default: 4, or 2 for more than 16 blocks
- * of canonical / compact cells), 1..4.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
+ * they share the write-out of every tile; 0 = chosen by the engine (default: 4 for Montgomery cells, else 4 / 2 / 1
+ * up to 16 / 64 / 128 blocks), 1..4.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
  * "chunk_blocks": blocks per kernel launch of a long batch (default and maximum 2^20; a test knob). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 

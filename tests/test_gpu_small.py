@@ -1,4 +1,4 @@
-"""The small-batch kernel (csrc/hsw_small.hpp): what every launch of <= 32 blocks uses -- the reference's own
+"""The small-batch kernel (csrc/hsw_small.hpp): what every launch of <= 128 blocks uses -- the reference's own
 bench circuit (benches/digest.rs: ONE 16-block digest) first of all.  37 waves per block, each running one
 SUB-UNIT program over 16 units with a register-latched chain; frames of whole digests in the same launch.
 Same cells as hsw_expand_kernel, bit for bit, and as the oracle."""
@@ -22,10 +22,10 @@ def _run(eng, blocks, pre, cursor0=0, flags=0):
     return {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in out.items()}
 
 
-@pytest.mark.parametrize("n", [1, 2, 16, 31, 32, 33])
+@pytest.mark.parametrize("n", [1, 2, 16, 31, 33, 128, 129])
 @pytest.mark.parametrize("ncols,cursor0", [(2, 0), (3, 5)])
 def test_small_kernel_gives_identical_streams(hsw, oracle, n, ncols, cursor0):
-    """Default engine: <= 32 blocks -> hsw_small_kernel, 33 -> hsw_expand_kernel; both against the oracle."""
+    """Default engine: <= 128 blocks -> hsw_small_kernel, 129 -> hsw_expand_kernel; both against the oracle."""
     eng = hsw.WitnessEngine(0, 8, ncols)
     blocks, pre = _inputs(n, 900 + n)
     blocks[0] = 0
@@ -36,8 +36,8 @@ def test_small_kernel_gives_identical_streams(hsw, oracle, n, ncols, cursor0):
     ref = oracle.Oracle(8, ncols, check=True).witness_blocks(blocks, pre, cursor0=cursor0)
     got = _run(eng, blocks, pre, cursor0=cursor0)
     li = eng.last_launch()
-    assert li["split"] == (2 if n <= 32 else 0) and ("hsw_small_kernel" in li["kernel"]) == (n <= 32)
-    assert li["grid"] == (37 * n if n <= 32 else li["parts"] * n)
+    assert li["split"] == (2 if n <= 128 else 0) and ("hsw_small_kernel" in li["kernel"]) == (n <= 128)
+    assert li["grid"] == (37 * n if n <= 128 else li["parts"] * n)
     g = got["gate"].view(np.uint64)
     if not np.array_equal(g, ref["gate"]):
         bad = np.nonzero((g != ref["gate"]).any(axis=1))[0]
@@ -164,7 +164,7 @@ def test_one_launch_whole_digest_equals_two_launches(hsw, oracle, mont):
 @pytest.mark.parametrize("internals", [False, True])
 @pytest.mark.parametrize("flags_name", ["canonical", "montgomery", "compact"])
 def test_helper_waves(hsw, oracle, helpers, internals, flags_name):
-    """A workgroup of the small-batch kernel is "helpers" waves (default 4, or 2 for more than 16 blocks of canonical / compact cells): wave 0 emits, and all of them share
+    """A workgroup of the small-batch kernel is "helpers" waves (default 4 for Montgomery cells, else 4 / 2 / 1 up to 16 / 64 / 128 blocks): wave 0 emits, and all of them share
     the conversion and write-out of every tile.  Any count gives the cells of the streaming kernel, and of
     the oracle."""
     import torch
@@ -188,7 +188,7 @@ def test_helper_waves(hsw, oracle, helpers, internals, flags_name):
 
     got = run()
     li = eng.last_launch()
-    h = helpers if helpers else (4 if flags_name == "montgomery" else 2)      # 18 blocks: 2 unless Montgomery
+    h = helpers if helpers else (4 if flags_name == "montgomery" else 2)      # 18 blocks: 2 (17 .. 64) unless Montgomery
     assert li["split"] == 2 and li["parts"] == 37 * h and li["grid"] == 37 * n
     eng.set_option("split", 0)
     ref = run()
