@@ -83,7 +83,7 @@ class Fuzzer:
         internals = bool(rng.integers(0, 2))
         bits = int(rng.choice([16, 8, 8, 4, 2, 1]))
         ncols = int(rng.integers(1, 7))
-        n = int(rng.choice([1, 2, 3, 5, 8, 13, 31, 32, 33, 40]))
+        n = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 32, 33, 40, 65, 128, 129]))
         if bits <= 2:
             n = min(n, 8)
         cursor0 = int(rng.choice([0, 1, int(rng.integers(0, 10**6)), int(rng.integers(0, 2**40))]))
@@ -91,11 +91,12 @@ class Fuzzer:
         tile, parts = [(0, 0), (32, 1), (32, 4), (32, 32), (64, 2), (64, 4), (64, 16), (128, 4), (128, 8), (128, 32),
                        (0, 1), (0, 8)][int(rng.integers(0, 12))]
         split = int(rng.choice([-1, -1, 0, 1, 2]))
+        helpers = int(rng.integers(0, 5))                          # waves per workgroup of the small-batch kernel
         shift = int(rng.choice([0, 0, 1, 2, 3]))
         pack = rng.random() < 0.4
         chunk = int(rng.choice([1 << 20, 1 << 20, 1, 3, 5]))      # blocks per launch: reach the multi-launch loop
         desc = dict(kind="blocks", internals=internals, bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags,
-                    tile=tile, parts=parts, split=split, shift=shift, pack=pack, chunk=chunk)
+                    tile=tile, parts=parts, split=split, helpers=helpers, shift=shift, pack=pack, chunk=chunk)
         self.current = desc
         eng = self.engine(bits, ncols, internals)
         G, LK = eng.G, eng.lookup_cells
@@ -136,6 +137,7 @@ class Fuzzer:
         eng.set_option("tile", tile)
         eng.set_option("parts", parts)
         eng.set_option("split", split)
+        eng.set_option("helpers", helpers)
         eng.set_option("chunk_blocks", chunk)
         try:
             rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
@@ -148,6 +150,7 @@ class Fuzzer:
             eng.set_option("tile", 0)
             eng.set_option("parts", 0)
             eng.set_option("split", -1)
+            eng.set_option("helpers", 0)
             eng.set_option("chunk_blocks", 1 << 20)
         ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=cursor0)
         eg, ed, es, el = self._expected(ref, eng, n, flags, internals)
