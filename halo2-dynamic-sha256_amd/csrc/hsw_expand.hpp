@@ -321,7 +321,12 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
     // paths; only a flush that straddles a break places every piece on its own (`packed`).
     u32 shift = 0;
     bool packed = false;
-    const u32 lo_c = em.cell_base + (u32)fl * (u32)T - skew;                           // LDS column 0 of row 0
+    // LDS column 0 of row 0 as a block-local cell index.  The block's very first tile (cell_base = 0, fl = 0)
+    // of a skewed unit has nothing in its columns below `skew`: clamp instead of wrapping below zero (the
+    // wrapped value compared as "past every break" and shifted the whole flush by the gap of a break that
+    // lay just behind it -- found by tests/fuzz_parity.py seed 77031).
+    const u32 lo_raw = em.cell_base + (u32)fl * (u32)T;
+    const u32 lo_c = lo_raw >= skew ? lo_raw - skew : 0u;
     if (em.brk1 != 0xffffffffu) {
         const u32 hi_c = lo_c + (em.nrows ? em.nrows - 1u : 0u) * em.unit_cells + (u32)T + 8u;   // past the last row's last piece
         if (em.brk1 >= hi_c) shift = 0;

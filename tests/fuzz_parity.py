@@ -78,7 +78,8 @@ class Fuzzer:
                     lookup[:, :1] if lookup is not None else None)
         return ref["gate"], ref["dense"], ref["spread"], lookup
 
-    def block_case(self):
+    def block_case(self, override=None):
+        """override: a FAILED-case dict to replay (its layout parameters; the data is drawn afresh)."""
         rng, N, t = self.rng, self.N, self.torch
         internals = bool(rng.integers(0, 2))
         bits = int(rng.choice([16, 8, 8, 4, 2, 1]))
@@ -95,6 +96,10 @@ class Fuzzer:
         shift = int(rng.choice([0, 0, 1, 2, 3]))
         pack = rng.random() < 0.4
         chunk = int(rng.choice([1 << 20, 1 << 20, 1, 3, 5]))      # blocks per launch: reach the multi-launch loop
+        if override:
+            internals, bits, ncols, n, cursor0, flags = (override[k] for k in ("internals", "bits", "ncols", "n", "cursor0", "flags"))
+            tile, parts, split, shift, pack, chunk = (override[k] for k in ("tile", "parts", "split", "shift", "pack", "chunk"))
+            helpers = override.get("helpers", 0)
         desc = dict(kind="blocks", internals=internals, bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags,
                     tile=tile, parts=parts, split=split, helpers=helpers, shift=shift, pack=pack, chunk=chunk)
         self.current = desc
@@ -104,6 +109,8 @@ class Fuzzer:
         if pack:
             max_rows = int(rng.integers(G // 2 + 16, 3 * G))
             start_row = int(rng.integers(0, max_rows))
+            if override:
+                start_row, max_rows = override["start_row"], override["max_rows"]
             desc.update(start_row=start_row, max_rows=max_rows)
             try:
                 plan = N.pack_plan(eng.shape, n, start_row, max_rows)
@@ -137,7 +144,8 @@ class Fuzzer:
         eng.set_option("tile", tile)
         eng.set_option("parts", parts)
         eng.set_option("split", split)
-        eng.set_option("helpers", helpers)
+        if helpers:
+            eng.set_option("helpers", helpers)
         eng.set_option("chunk_blocks", chunk)
         try:
             rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
@@ -150,7 +158,8 @@ class Fuzzer:
             eng.set_option("tile", 0)
             eng.set_option("parts", 0)
             eng.set_option("split", -1)
-            eng.set_option("helpers", 0)
+            if helpers:
+                eng.set_option("helpers", 0)
             eng.set_option("chunk_blocks", 1 << 20)
         ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=cursor0)
         eg, ed, es, el = self._expected(ref, eng, n, flags, internals)
@@ -178,7 +187,13 @@ class Fuzzer:
         got = flat[idx]
         if not np.array_equal(got, eg):
             bad = np.nonzero((got != eg).any(axis=1))[0]
-            raise AssertionError("gate stream differs at %d cells, first %d" % (len(bad), bad[0]))
+            stray = np.ones(flat.shape[0], dtype=bool)
+            stray[idx] = False
+            stray = np.nonzero(stray & (flat != FILL).any(axis=1))[0]      # written, but not a place of the stream
+            raise AssertionError("gate stream differs at %d cells, first %d (block %d cell %d; all: %s); got %s expected %s; "
+                                 "buffer places of the bad cells %s; written outside the stream: %s" % (
+                len(bad), bad[0], bad[0] // G, bad[0] % G, [int(b) for b in bad[:48]], got[bad[0]], eg[bad[0]],
+                [int(i) for i in idx[bad[:48]]], [int(i) for i in stray[:48]]))
         mask = np.ones(flat.shape[0], dtype=bool)
         mask[idx] = False
         assert (flat[mask] == FILL).all(), "cells outside the stream were written"
@@ -470,6 +485,17 @@ class Fuzzer:
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "replay":      # python tests/fuzz_parity.py replay "<FAILED case dict>" [seed]
+        import ast
+        f = Fuzzer(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+        case = ast.literal_eval(sys.argv[2])
+        assert case["kind"] == "blocks", "only block cases replay"
+        try:
+            f.block_case(override=case)
+            print("replay: clean")
+        finally:
+            f.close()
+        sys.exit(0)
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     f = Fuzzer(seed)

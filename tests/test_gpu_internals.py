@@ -140,6 +140,78 @@ def test_flexgate_column_packing(hsw, oracle, eng_int, engine_factory, internals
     assert plan.columns_touched == max(c for c, _ in pos) + 1
 
 
+def _break_right_after_a_skewed_block_start(shape, n, rng, window):
+    """(start_row, max_rows) whose plan puts a column break within `window` cells after the start of a block
+    that does not start on a 128-byte line -- the corner tests/fuzz_parity.py seed 77031 found."""
+    import importlib
+    N = importlib.import_module("halo2-dynamic-sha256_amd._native")
+    G = int(shape.gate_cells_per_block)
+    for _ in range(20000):
+        max_rows = int(rng.integers(G // 2 + 16, 3 * G))
+        start_row = int(rng.integers(0, max_rows))
+        try:
+            plan = N.pack_plan(shape, n, start_row, max_rows)
+        except N.HswError:
+            continue
+        gap = 0
+        for k in range(plan.n_breaks):
+            bc = int(plan.break_cell[k])
+            if 0 < bc % G <= window and ((bc - bc % G) + gap) % 4 != 0:
+                return start_row, max_rows, bc // G, bc % G
+            gap += int(plan.break_gap[k])
+    raise AssertionError("no such layout found")
+
+
+@pytest.mark.parametrize("tile,parts,window", [(0, 0, 60), (128, 8, 150), (128, 4, 150), (64, 4, 100), (32, 2, 40)])
+@pytest.mark.parametrize("mont", [False, True])
+def test_column_break_right_after_a_skewed_block_start(hsw, oracle, tile, parts, window, mont):
+    """A break that lands inside the first flush of a block whose stream does not start on a 128-byte line:
+    the realigning write-out's bounds must not wrap below the block's first cell (they did: the flush was
+    taken to lie past the break and shifted by its gap).  The fuzz's own failing case first, then layouts
+    searched for per tile shape."""
+    import ctypes as C
+    import torch
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 4, mode=N.HSW_MODE_HALO2_INTERNALS)
+    n = 13
+    rng = np.random.default_rng(77031 + tile + parts)
+    layouts = [(70699, 109190)] if tile == 128 else []
+    for _ in range(3):
+        layouts.append(_break_right_after_a_skewed_block_start(eng.shape, n, rng, window)[:2])
+    blocks, pre = _inputs(n, 4100 + tile)
+    ref = oracle.Oracle(8, 4, check=False, internals=True).witness_blocks(blocks, pre)
+    exp = oracle.to_montgomery(ref["gate"]) if mont else ref["gate"]
+    lens = N.gate_tape(eng.shape)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    eng.set_option("tile", tile)
+    eng.set_option("parts", parts)
+    eng.set_option("split", 0)                          # the streaming kernel (the small-batch one never realigns)
+    for start_row, max_rows in layouts:
+        plan = N.pack_plan(eng.shape, n, start_row, max_rows)
+        gate = torch.full((int(plan.span_cells), 4), -1, dtype=torch.int64, device="cuda")
+        rows = eng.chip_rows(0, n)
+        dense = torch.zeros((4, rows, 4), dtype=torch.int64, device="cuda")
+        spread = torch.zeros((4, rows, 4), dtype=torch.int64, device="cuda")
+        lookup = torch.empty((n * eng.lookup_cells, 4), dtype=torch.int64, device="cuda")
+        a = N.WitnessArgs()
+        a.d_blocks, a.d_pre_states, a.n_blocks, a.spread_cursor0 = tb.data_ptr(), tp.data_ptr(), n, 0
+        a.d_gate, a.d_chip_dense, a.d_chip_spread, a.chip_col_stride = gate.data_ptr(), dense.data_ptr(), spread.data_ptr(), rows
+        a.d_next_states, a.d_lookup, a.pack = None, lookup.data_ptr(), C.pointer(plan)
+        a.flags = N.HSW_REPR_MONTGOMERY if mont else 0
+        rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
+        assert rc == 0, eng.lib.hsw_last_error(eng.h)
+        eng.synchronize()
+        pos = _model_positions(lens, n, start_row, max_rows)
+        idx = np.array([c * max_rows + r - start_row for c, r in pos], dtype=np.int64)
+        flat = gate.cpu().numpy().view(np.uint64)
+        bad = np.nonzero((flat[idx] != exp).any(axis=1))[0]
+        assert len(bad) == 0, (start_row, max_rows, len(bad), int(bad[0]) // eng.G, int(bad[0]) % eng.G)
+        mask = np.ones(flat.shape[0], dtype=bool)
+        mask[idx] = False
+        assert (flat[mask] == np.uint64(2**64 - 1)).all(), (start_row, max_rows)
+    eng.close()
+
+
 @pytest.mark.parametrize("flags_name", ["HSW_REPR_MONTGOMERY", "HSW_REPR_COMPACT64"])
 def test_packing_combined_with_other_representations(hsw, oracle, eng_int, flags_name):
     """Column packing + internals + a non-default cell representation in one call."""
