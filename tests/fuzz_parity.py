@@ -109,6 +109,21 @@ class Fuzzer:
         if pack:
             max_rows = int(rng.integers(G // 2 + 16, 3 * G))
             start_row = int(rng.integers(0, max_rows))
+            aim = rng.random()
+            if aim < 0.5 and not override:
+                # half of the packed cases aim a column break at the first / last cells of a block (the first and
+                # the last flush of a block are special cases of the realigning write-out)
+                for _ in range(400):
+                    mr, sr = int(rng.integers(G // 2 + 16, 3 * G)), 0
+                    sr = int(rng.integers(0, mr))
+                    try:
+                        pl = N.pack_plan(eng.shape, n, sr, mr)
+                    except N.HswError:
+                        continue
+                    at = [int(pl.break_cell[k]) % G for k in range(pl.n_breaks)]
+                    if any((0 < c <= 160) if aim < 0.25 else (c >= G - 160) for c in at):
+                        max_rows, start_row = mr, sr
+                        break
             if override:
                 start_row, max_rows = override["start_row"], override["max_rows"]
             desc.update(start_row=start_row, max_rows=max_rows)
