@@ -452,8 +452,10 @@ __global__ __launch_bounds__(64 * HSW_SMALL_MAX_HELPERS) void hsw_small_kernel(E
         }
     }
 
-    const size_t blk = blockIdx.x / SMALL_ROLES;
-    const u32 role = blockIdx.x % SMALL_ROLES;
+    // role-major grid: the workgroups with the longest chains (of every block) are dispatched first -- a launch
+    // of 600 workgroups takes ~1.5 us to be handed out, and that should fall on the short roles
+    const u32 role = blockIdx.x / (u32)p.n_blocks;
+    const size_t blk = blockIdx.x - role * (u32)p.n_blocks;
     const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
     u32 ps[8];                                   // this block's pre-state (wave-uniform)
     if (p.flags & HSW_K_CHAINED) {

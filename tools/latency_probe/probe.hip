@@ -82,17 +82,21 @@ int main(int argc, char **argv) {
         }
         // per-wave durations of the split-mode programs of block 0
         if (c.tile < 0) {
+            const size_t NBs = NB;      // the small-batch kernel's grid is role-major: (block 0, role w) is workgroup w * NB
             printf("   block 0, roles 0..32: emission+full flushes / last flush / chip scatter / rest (us)\n   ");
             for (unsigned w = 0; w < 33; w++)
-                printf("[%u] %.1f/%.1f/%.1f/%.1f  ", w, (st[w * 16 + 5] - st[w * 16 + 2]) * 0.01, (st[w * 16 + 6] - st[w * 16 + 5]) * 0.01,
-                       (st[w * 16 + 7] - st[w * 16 + 6]) * 0.01, (st[w * 16 + 4] - st[w * 16 + 7]) * 0.01);
+                printf("[%u] %.1f/%.1f/%.1f/%.1f  ", w, (st[w * NBs * 16 + 5] - st[w * NBs * 16 + 2]) * 0.01, (st[w * NBs * 16 + 6] - st[w * NBs * 16 + 5]) * 0.01,
+                       (st[w * NBs * 16 + 7] - st[w * NBs * 16 + 6]) * 0.01, (st[w * NBs * 16 + 4] - st[w * NBs * 16 + 7]) * 0.01);
             printf("\n");
         }
         if ((c.flags & hsw::HSW_K_SPLIT) || c.tile < 0) {
             printf("   block 0, per wave: chain / seeds / program (us)\n   ");
             for (unsigned w = 0; w < wpb; w++)
-                printf("[%u] %.1f/%.1f/%.1f  ", w, (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 2] - st[w * 16 + 1]) * 0.01,
-                       (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01);
+            {
+                const size_t x = c.tile < 0 ? (size_t)w * NB : w;
+                printf("[%u] %.1f/%.1f/%.1f  ", w, (st[x * 16 + 1] - st[x * 16]) * 0.01, (st[x * 16 + 2] - st[x * 16 + 1]) * 0.01,
+                       (st[x * 16 + 4] - st[x * 16 + 2]) * 0.01);
+            }
             printf("\n");
         }
     }
@@ -145,11 +149,14 @@ int main(int argc, char **argv) {
         for (size_t w = 0; w < NB * 37; w++) mx = std::max(mx, (st[w * 16 + 4] - t0) * 0.01);
         printf("   block 0, per wave: chain / seeds / program (us)\n   ");
         for (unsigned w = 0; w < 37; w++)
-            printf("[%u] %.1f/%.1f/%.1f  ", w, (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 2] - st[w * 16 + 1]) * 0.01,
-                   (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01);
+        {
+            const size_t x = (size_t)w * NB;       // role-major grid
+            printf("[%u] %.1f/%.1f/%.1f  ", w, (st[x * 16 + 1] - st[x * 16]) * 0.01, (st[x * 16 + 2] - st[x * 16 + 1]) * 0.01,
+                   (st[x * 16 + 4] - st[x * 16 + 2]) * 0.01);
+        }
         printf("\n   block %zu, per wave: chain / seeds / program (us)\n   ", NB - 1);
         for (unsigned w = 0; w < 37; w++) {
-            const size_t x = (NB - 1) * 37 + w;
+            const size_t x = (size_t)w * NB + (NB - 1);
             printf("[%u] %.1f/%.1f/%.1f  ", w, (st[x * 16 + 1] - st[x * 16]) * 0.01, (st[x * 16 + 2] - st[x * 16 + 1]) * 0.01,
                    (st[x * 16 + 4] - st[x * 16 + 2]) * 0.01);
         }
@@ -161,7 +168,7 @@ int main(int argc, char **argv) {
             printf("\n   entry: median %.2f  p90 %.2f  max %.2f us;  latest exits:", en[en.size() / 2], en[en.size() * 9 / 10], en.back());
             for (size_t i = ex.size() - 6; i < ex.size(); i++) {
                 const size_t w = ex[i].second;
-                printf("  [blk %zu role %zu: entry %.1f chain %.1f prog %.1f exit %.1f]", w / 37, w % 37, (st[w * 16] - t0) * 0.01,
+                printf("  [blk %zu role %zu: entry %.1f chain %.1f prog %.1f exit %.1f]", w % NB, w / NB, (st[w * 16] - t0) * 0.01,
                        (st[w * 16 + 1] - st[w * 16]) * 0.01, (st[w * 16 + 4] - st[w * 16 + 2]) * 0.01, ex[i].first);
             }
         }
