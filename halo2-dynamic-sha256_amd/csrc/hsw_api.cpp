@@ -470,6 +470,8 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             const uint32_t helpers = e->helpers ? (uint32_t)e->helpers
                                      : ((flags & HSW_REPR_MONTGOMERY) || n <= 16) ? 4u : n <= 64 ? 2u : 1u;
             p.parts = helpers;
+            if (n <= 16) p.flags |= hsw::HSW_K_ROLE_MAJOR;
+            else p.flags &= ~(uint32_t)hsw::HSW_K_ROLE_MAJOR;
             p.next_states_host = host_next_states ? host_next_states + 8 * done : nullptr;
             he = hsw::launch_small(p, done == 0 ? frames : nullptr, e->limbs, e->stream);
             if (he != hipSuccess) return set_err(e, HSW_ERR_HIP, "launch hsw_small_kernel", he);

@@ -17,6 +17,7 @@ enum : uint32_t {
     HSW_K_INTERNALS = 16u,   // engine mode HSW_MODE_HALO2_INTERNALS: range_check cells + lookup stream
     HSW_K_SPLIT = 32u,       // 32 waves per block, each running one phase program (tiny batches: latency)
     HSW_K_CHAINED = 64u,     // small-batch kernel: the blocks are ONE message, pre_states holds its initial state only
+    HSW_K_ROLE_MAJOR = 128u, // small-batch kernel: grid = role x block instead of block x role (hsw_small.hpp)
 };
 enum { HSW_K_MAX_BREAKS = 16 };
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)

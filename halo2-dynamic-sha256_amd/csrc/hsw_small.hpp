@@ -61,7 +61,6 @@ enum : u32 {
     SMALL_ROWS = 16, SMALL_TILE = 128,
 };
 static_assert(SMALL_ROLES == HSW_SMALL_WAVES_PER_BLOCK, "hsw_kernels.h");
-
 // The plain SHA-256 recurrence of one block, wave-uniform, through registers.  Index convention: A_t / E_t
 // are the a / e words at the START of round t (A_0 = a, A_-1 = b, A_-2 = c, A_-3 = d of the pre-state; round
 // t works on a..d = A_t..A_t-3, e..h = E_t..E_t-3), W_t the schedule word of round t.  Runs rounds
@@ -452,10 +451,13 @@ __global__ __launch_bounds__(64 * HSW_SMALL_MAX_HELPERS) void hsw_small_kernel(E
         }
     }
 
-    // role-major grid: the workgroups with the longest chains (of every block) are dispatched first -- a launch
-    // of 600 workgroups takes ~1.5 us to be handed out, and that should fall on the short roles
-    const u32 role = blockIdx.x / (u32)p.n_blocks;
-    const size_t blk = blockIdx.x - role * (u32)p.n_blocks;
+    // Grid order.  Block-major, or (HSW_K_ROLE_MAJOR, launches of <= 16 blocks) role-major: the workgroups of one
+    // role -- the same instructions -- then sit next to each other.  Same-box A/B through the C ABI: 16
+    // Montgomery blocks 34.5 -> 32.6 us, canonical unchanged, 32 Montgomery blocks 47.1 -> 48.9 us (hence the
+    // limit); a longest-roles-first permutation on top of it changed nothing (workgroups do not start in grid order).
+    const bool role_major = (p.flags & HSW_K_ROLE_MAJOR) != 0u;
+    const u32 role = role_major ? blockIdx.x / (u32)p.n_blocks : blockIdx.x % SMALL_ROLES;
+    const size_t blk = role_major ? blockIdx.x - role * (u32)p.n_blocks : blockIdx.x / SMALL_ROLES;
     const u32 *bw = reinterpret_cast<const u32 *>(p.blocks + 64 * blk);
     u32 ps[8];                                   // this block's pre-state (wave-uniform)
     if (p.flags & HSW_K_CHAINED) {

@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = d_gate; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
-        p.flags = c.flags; p.parts = c.parts;
+        p.flags = c.flags | (c.tile < 0 ? hsw::HSW_K_ROLE_MAJOR : 0u); p.parts = c.parts;
         std::vector<float> ms;
         for (int i = 0; i < 12; i++) {
             CK(hipMemset(d_st, 0, NB * 64 * 16 * 8));
@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
         }
         // per-wave durations of the split-mode programs of block 0
         if (c.tile < 0) {
-            const size_t NBs = NB;      // the small-batch kernel's grid is role-major: (block 0, role w) is workgroup w * NB
+            const size_t NBs = NB;      // the small-batch kernel's grid is slot-major: (block 0, role w) is workgroup (size_t)w * NB
             printf("   block 0, roles 0..32: emission+full flushes / last flush / chip scatter / rest (us)\n   ");
             for (unsigned w = 0; w < 33; w++)
                 printf("[%u] %.1f/%.1f/%.1f/%.1f  ", w, (st[w * NBs * 16 + 5] - st[w * NBs * 16 + 2]) * 0.01, (st[w * NBs * 16 + 6] - st[w * NBs * 16 + 5]) * 0.01,
@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
         hsw::ExpandParams p{};
         p.blocks = d_blocks; p.pre_states = d_pre; p.gate = (char *)d_gate2 + (PL + 1) * 32; p.chip_dense = d_cd; p.chip_spread = d_cs;
         p.next_states = d_next; p.n_blocks = NB; p.chip_col_stride = NB * LC / 2; p.cursor0 = 0; p.ncols = 2;
-        p.flags = hsw::HSW_K_INTERNALS | (mont ? hsw::HSW_K_MONTGOMERY : 0u); p.parts = 4;
+        p.flags = hsw::HSW_K_INTERNALS | hsw::HSW_K_ROLE_MAJOR | (mont ? hsw::HSW_K_MONTGOMERY : 0u); p.parts = 4;
         p.lookup = (char *)d_lk + (3 + 2 * 64 * NB) * 32;
         p.frame_every = NB; p.frame_cells = PL + EL; p.frame_lookups = 3 + 2 * 64 * NB + 64;
         hsw::SmallFrames fr{};
@@ -150,7 +150,7 @@ int main(int argc, char **argv) {
         printf("   block 0, per wave: chain / seeds / program (us)\n   ");
         for (unsigned w = 0; w < 37; w++)
         {
-            const size_t x = (size_t)w * NB;       // role-major grid
+            const size_t x = (size_t)w * NB;       // slot-major grid
             printf("[%u] %.1f/%.1f/%.1f  ", w, (st[x * 16 + 1] - st[x * 16]) * 0.01, (st[x * 16 + 2] - st[x * 16 + 1]) * 0.01,
                    (st[x * 16 + 4] - st[x * 16 + 2]) * 0.01);
         }
