@@ -437,9 +437,8 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     // Tiny batches (the reference's bench circuit is ONE 16-block digest) are latency-bound: they go to the
     // small-batch kernel, which for a whole-digest context also writes the frames -- ONE launch, inputs read
     // in place from the pinned staging, next states written straight into pinned memory, no copy launches.
-    bool one_run = true;                       // whole-digest contexts: all digests of the batch equally sized
-    for (size_t i = 1; i < n; i++) one_run = one_run && plans[i].max_variable_round == plans[0].max_variable_round;
-    const bool small = hsw_small_eligible(ctx.engine, batch_blocks) && (!ctx.whole || one_run);
+    // (whole-digest contexts: one such launch per run of equally sized digests, each with its own frames)
+    const bool small = hsw_small_eligible(ctx.engine, batch_blocks);
     const bool zero_copy = host_chain && (ctx.whole ? small : (small || batch_blocks <= 32));
     const uint8_t *in_blocks = zero_copy ? ctx.dp_blocks : ctx.d_blocks;        // bases, indexed by absolute block
     const uint32_t *in_pre = zero_copy ? ctx.dp_pre : ctx.d_pre_states;
@@ -519,7 +518,6 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
             ob = 0;
             for (size_t i = 0; i < n && rc == HSW_OK;) {
                 size_t j = i + 1;                            // run [i, j) of equally sized digests
-                if (small) j = n;                            // (one_run) all of them, frames included, in one launch
                 while (j < n && frames[j].n_blocks == frames[i].n_blocks) j++;
                 const size_t nb = frames[i].n_blocks, run_blocks = nb * (j - i);
                 const uint64_t cursor = ctx.num_limb_sum + (uint64_t)ob * ctx.shape.limb_calls_per_block;
@@ -553,7 +551,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                 if (small) {
                     hsw_digests_args da{};
                     da.blocks = a;
-                    da.descs = frames.data(); da.n_digests = n;
+                    da.descs = frames.data() + i; da.n_digests = j - i;      // this run's digests: frames in the same launch
                     da.d_blocks0 = in_blocks; da.d_pre_states0 = in_pre; da.d_next_states0 = ctx.d_next_states;
                     da.d_gate0 = ctx.d_gate; da.d_lookup0 = ctx.d_lookup;
                     hsw_pack_plan abs_plan{};
@@ -563,7 +561,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                         abs_plan.break_gap[k] = ctx.break_gap[k];
                     }
                     da.frame_pack = ctx.max_rows ? &abs_plan : nullptr;
-                    da.host_next_states = h_next;
+                    da.host_next_states = h_next + 8 * ob;
                     rc = hsw_witness_digests(ctx.engine, &da);
                     next_in_pinned = rc == HSW_OK;
                 } else {
