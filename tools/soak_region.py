@@ -12,9 +12,9 @@ only_small = len(sys.argv) > 2 and sys.argv[2] == "small"      # the small-batch
 eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
 rng = np.random.default_rng(5)
 configs = []
-# the last three are small-batch launches (<= 128 blocks): workgroups of up to 4 waves sharing one tile, frames in the same grid
+# the last four are small-batch launches (the very last of mixed sizes: one fused launch per run of equal sizes) (<= 128 blocks): workgroups of up to 4 waves sharing one tile, frames in the same grid
 for nd, sizes in [(512, [64] * 512), (96, [192] * 96), (40, [64, 128, 256, 64] * 10),
-                  (1, [1024]), (8, [960] * 8), (2, [128, 128])]:
+                  (1, [1024]), (8, [960] * 8), (2, [128, 128]), (6, [64, 128, 256, 64, 64, 192])]:
     if only_small and nd > 8:
         continue
     for rep in (0, N.HSW_REPR_MONTGOMERY):
