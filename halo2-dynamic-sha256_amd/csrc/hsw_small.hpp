@@ -1,17 +1,19 @@
-// hsw_small.hpp -- the expansion kernel for SMALL batches (<= 32 blocks per launch: the reference's own
-// bench circuit, benches/digest.rs:93,102-109,129, is ONE 56-byte message = 16 blocks).
+// hsw_small.hpp -- the expansion kernel for SMALL batches (<= 128 blocks per launch by default: the
+// reference's own bench circuit, benches/digest.rs:93,102-109,129, is ONE 56-byte message = 16 blocks).
 //
-// Such a launch writes ~40 MB: it is bound by latency -- launch + the 64-round chain of one block + the
+// A 16-block launch writes ~40 MB: it is bound by latency -- launch + the 64-round chain of one block + the
 // longest program a wave runs -- not by HBM.  hsw_expand_kernel (hsw_expand.hpp) deals whole units to lanes
 // (lane = round), which is the right shape for 4,096 blocks and the wrong one for 16: with 16 waves per
 // block on the rounds, 4 of 64 lanes work through a 760-cell straight-line program (17 us measured, after
 // 6.4 us of chain and 0.7 us of seed staging through LDS; tools/latency_probe).  Here instead:
 //
-//  * a wave = one ROLE: a SUB-UNIT program (a round is six of them -- Sigma1 | ch, first half | ch, second
+//  * a workgroup = one ROLE: a SUB-UNIT program (a round is six of them -- Sigma1 | ch, first half | ch, second
 //    half + T1 | Sigma0 | maj + T2 | the two state updates, independent once the chain seeds are known,
-//    compression.rs:125-196; a schedule step is three) over 16 consecutive units, lane = unit.  37 waves per
-//    block, the longest program is a sigma's 138 cells instead of a round's 760, [16 rows][128 cells] tiles.
-//  * the chain is recomputed by every wave, wave-uniform, but only as far as the wave needs it (rounds
+//    compression.rs:125-196; a schedule step is three) over 16 consecutive units, lane = unit.  37 workgroups
+//    per block, the longest program is a sigma's 138 cells instead of a round's 760, [16 rows][128 cells] tiles.
+//  * up to 4 waves per workgroup (Em::HELPERS, hsw_expand.hpp): wave 0 emits, and all of them share the
+//    conversion and write-out of every tile -- that, not the emission, is most of a role's program.
+//  * the chain is recomputed by every emitter wave, wave-uniform, but only as far as the wave needs it (rounds
 //    0..15 need 15 rounds of it, schedule waves none), straight through registers: lane l LATCHES the a / e /
 //    W value born at its own index (one compare + select per value) and fetches its neighbours' with
 //    ds_bpermute -- no LDS staging, no stores, and the bit operations are v_bitop3 / v_add3.
@@ -52,7 +54,7 @@ struct SmallPlan {
     static constexpr int MAX_LK = 8;
 };
 
-// Roles of the waves of one block, longest chains first (dispatch order = blockIdx order).
+// Roles of the workgroups of one block.
 enum : u32 {
     SMALL_ROUND_ROLES = 24,   // role = type * 4 + (3 - range): 6 sub-unit types x 4 ranges of 16 rounds
     SMALL_SCHED_ROLES = 9,    // role - 24 = type * 3 + (2 - range): 3 sub-unit types x 3 ranges of 16 steps
