@@ -319,7 +319,7 @@ extern "C" {
     pub fn hsw_engine_stream(e: *const hsw_engine, hip_stream: *mut *mut c_void, device: *mut c_int) -> c_int;
     pub fn hsw_engine_set_option(e: *mut hsw_engine, name: *const c_char, value: i64) -> c_int;
     pub fn hsw_last_launch(e: *const hsw_engine, out: *mut hsw_launch_info) -> c_int;
-    /// Block streams and frames of n equally sized digests in one call (one kernel launch up to 32 blocks).
+    /// Block streams and frames of n equally sized digests in one call (one kernel launch up to 128 blocks, in digests of up to 32).
     pub fn hsw_witness_digests(e: *mut hsw_engine, args: *const hsw_digests_args) -> c_int;
     pub fn hsw_gadget_result_cells(g: *const hsw_gadget, hash_idx: usize, out: *mut hsw_result_cells) -> c_int;
     pub fn hsw_gadget_download_region_compact(g: *mut hsw_gadget, dst: *mut hsw_region_compact) -> c_int;
