@@ -4,7 +4,7 @@ off, canonical / Montgomery cells, FlexGate columns of a random height (so the c
 the frames and block streams), streaming kernel ("split" = 0) or the engine's own choice.  The verifier
 (hsw_gadget_verify) checks every gate row, copy, range bound and chip tie at the place the constraint structure
 expects it, independently of the write-out logic -- a misplaced flush shows up as violations.
-usage: soak_layouts.py [seconds] [seed]"""
+usage: soak_layouts.py [seconds] [seed] [num_advice_columns of the spread chip, default 2]"""
 import importlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,8 @@ hsw = importlib.import_module("halo2-dynamic-sha256_amd")
 N = hsw._native
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
-eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+ncols = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+eng = hsw.WitnessEngine(0, 8, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
 G = eng.G
 t0 = time.time()
 layouts = checks = skipped = 0
