@@ -3,7 +3,7 @@
 mode), each verified on the device with hsw_verify_blocks under the same plan: tile shape, waves per block,
 kernel choice, helper waves, cell form, batch size, start row and column height are drawn at random; half of
 the layouts aim a column break at the first or last 160 cells of a block (the realigning write-out's corner
-cases).  No oracle on the CPU, so ~1 ms per case.  usage: soak_packs.py [seconds] [seed] [num_advice_columns]"""
+cases).  No oracle on the CPU, so ~1 ms per case.  usage: soak_packs.py [seconds] [seed] [num_advice_columns] [num_bits_lookup]"""
 import ctypes as C, importlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,14 +13,15 @@ import torch
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 ncols = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-eng = hsw.WitnessEngine(0, 8, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
+bits = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+eng = hsw.WitnessEngine(0, bits, ncols, mode=N.HSW_MODE_HALO2_INTERNALS)
 G, LK = eng.G, eng.lookup_cells
 KNOBS = [(0, 0), (32, 1), (32, 4), (32, 32), (64, 2), (64, 4), (64, 16), (128, 4), (128, 8), (128, 32), (0, 1), (0, 8)]
 t0 = time.time()
 last = t0
 cases = checks = skipped = aimed = 0
 while time.time() - t0 < secs:
-    n = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 33, 40, 65, 128, 129]))
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 31, 33, 40, 65, 128, 129] if bits >= 8 else [1, 2, 3, 5, 8]))
     mont = bool(rng.integers(0, 2))
     tile, parts = KNOBS[int(rng.integers(0, len(KNOBS)))]
     split = int(rng.choice([-1, 0, 0, 2]))
