@@ -40,6 +40,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "hsw_flush_bounds.hpp"
+
 #include "hsw_kernels.h"
 #include "hsw_layout.h"
 
@@ -281,7 +283,7 @@ using CurStart = Cur<0, 0>;
 // handful of VALU instructions instead of 64-bit pointer arithmetic per lane.
 template <class EM>
 DEV u32 packed_cell(const EM &em, u32 cl) {       // FlexGate column packing: add the gaps of the breaks passed
-    return cl + (cl >= em.brk1 ? em.gap1 : 0u) + (cl >= em.brk2 ? em.gap2 : 0u);
+    return packed_cell_of(BlockBreaks{em.brk1, em.gap1, em.brk2, em.gap2}, cl);
 }
 DEV void store16(char *base, u32 byte_off, uint4 v) { *reinterpret_cast<uint4 *>(base + (size_t)byte_off) = v; }
 DEV void store8(char *base, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(base + (size_t)byte_off) = v; }
@@ -319,32 +321,14 @@ DEV void flush_tile(EM &em, u32 ncells, int fl, int na, int nb, int nc, int nd, 
     // FlexGate column breaks inside this block (wave-uniform; none unless a pack plan is in force): a flush
     // whose cells all lie on one side of them is only SHIFTED by the gaps it has passed and keeps the fast
     // paths; only a flush that straddles a break places every piece on its own (`packed`).
-    u32 shift = 0;
+    // (hsw_flush_bounds.hpp: plain integer functions, property-tested on the CPU -- tests/test_flush_bounds.py)
+    const BlockBreaks bb{em.brk1, em.gap1, em.brk2, em.gap2};
+    const u32 lo_c = flush_lo_cell(em.cell_base, (u32)fl, (u32)T, skew);          // LDS column 0 of row 0
     bool packed = false;
-    // LDS column 0 of row 0 as a block-local cell index.  The block's very first tile (cell_base = 0, fl = 0)
-    // of a skewed unit has nothing in its columns below `skew`: clamp instead of wrapping below zero (the
-    // wrapped value compared as "past every break" and shifted the whole flush by the gap of a break that
-    // lay just behind it -- found by tests/fuzz_parity.py seed 77031).
-    const u32 lo_raw = em.cell_base + (u32)fl * (u32)T;
-    const u32 lo_c = lo_raw >= skew ? lo_raw - skew : 0u;
-    if (em.brk1 != 0xffffffffu) {
-        const u32 hi_c = lo_c + (em.nrows ? em.nrows - 1u : 0u) * em.unit_cells + (u32)T + 8u;   // past the last row's last piece
-        if (em.brk1 >= hi_c) shift = 0;
-        else if (em.brk1 <= lo_c && em.brk2 >= hi_c) shift = em.gap1;
-        else if (em.brk2 <= lo_c) shift = em.gap1 + em.gap2;
-        else packed = true;
-    }
+    const u32 shift = flush_shift(bb, lo_c, em.nrows, em.unit_cells, (u32)T, packed);
     // ... and inside a straddling flush every ROW is again either shifted as a whole or (at most two of them)
     // straddles a break itself: returns the row's shift, `strad` = place the row piece by piece
-    auto row_shift = [&](u32 r, bool &strad) -> u32 {
-        const u32 row_lo = lo_c + r * em.unit_cells, row_hi = row_lo + (u32)T + 8u;
-        strad = false;
-        if (em.brk1 >= row_hi) return 0u;
-        if (em.brk1 <= row_lo && em.brk2 >= row_hi) return em.gap1;
-        if (em.brk2 <= row_lo) return em.gap1 + em.gap2;
-        strad = true;
-        return 0u;
-    };
+    auto row_shift = [&](u32 r, bool &strad) -> u32 { return flush_row_shift(bb, lo_c, r, em.unit_cells, (u32)T, strad); };
     // A skewed unit shares its first line with the previous unit's tail, which is written at the END of
     // the phase: the first 4 - skew cells of every unit but the wave's first are held back in em.head and
     // appended to the previous row's tail in the last flush, so that the shared line is completed within
