@@ -15,20 +15,26 @@ static void die(const char *what, int rc, const hsw_engine *e) {
     exit(1);
 }
 
-/* the cell at (column, row) of the gadget's column image, as four little-endian limbs */
+/* the cell at FlexGate (column, row), as four little-endian limbs: image column = column - origin_column */
 static void read_cell(hsw_engine *eng, const hsw_gadget_view *v, const uint64_t pos[2], uint64_t out[4]) {
-    const int rc = hsw_download(eng, out, (const uint8_t *)v->d_gate + (pos[0] * v->max_rows + pos[1]) * HSW_CELL_BYTES, 32);
+    const int rc = hsw_download(eng, out, (const uint8_t *)v->d_gate +
+                                ((pos[0] - v->origin_column) * v->max_rows + pos[1]) * HSW_CELL_BYTES, 32);
     if (rc != HSW_OK) die("hsw_download", rc, eng);
 }
 
+/* origin: where the circuit's Context stands when it calls digest() for the first time -- (0, 0, fresh) for the
+ * reference's own circuits, anything for a circuit that has used the gate / range chips before */
+typedef struct { uint64_t column, row, lookups_queued; int zero_cell_loaded; } origin_t;
+
 static int check_circuit(const char *name, const size_t *sizes, size_t n, const uint8_t *const *msgs, const size_t *lens,
-                         uint64_t want_columns) {
+                         uint64_t want_columns, origin_t o) {
     hsw_engine *eng = NULL;
     int rc = hsw_engine_create_ex(0, NULL, 8, 2, HSW_MODE_HALO2_INTERNALS, &eng);
     if (rc != HSW_OK) die("hsw_engine_create_ex", rc, NULL);
     hsw_gadget *g = NULL;
     if ((rc = hsw_gadget_create_ex(eng, sizes, n, 1, HSW_GADGET_WHOLE_DIGEST, &g)) != HSW_OK) die("hsw_gadget_create_ex", rc, eng);
     uint64_t columns = 0;
+    if ((rc = hsw_gadget_set_origin(g, o.column, o.row, o.zero_cell_loaded, o.lookups_queued)) != HSW_OK) die("hsw_gadget_set_origin", rc, eng);
     if ((rc = hsw_gadget_set_columns(g, (1u << 17) - 9, &columns)) != HSW_OK) die("hsw_gadget_set_columns", rc, eng);
     if (columns != want_columns) { fprintf(stderr, "%s: %llu columns\n", name, (unsigned long long)columns); return 1; }
     hsw_hash_result r[4];
@@ -36,6 +42,15 @@ static int check_circuit(const char *name, const size_t *sizes, size_t n, const 
         if ((rc = hsw_gadget_digest(g, msgs[i], lens[i], 0, &r[i])) != HSW_OK) die("hsw_gadget_digest", rc, eng);
     hsw_gadget_view v;
     hsw_gadget_streams(g, &v);
+    /* the region, checked on the device against the constraint structure, wherever it starts */
+    hsw_verify_report rep;
+    if ((rc = hsw_gadget_verify(g, &rep)) != HSW_OK) die("hsw_gadget_verify", rc, eng);
+    if (rep.violations) { fprintf(stderr, "%s: %llu violations\n", name, (unsigned long long)rep.violations); return 1; }
+    /* the first cell of the first digest sits where the Context stood; its lookups follow the queued ones */
+    if (r[0].prologue_lookup != o.lookups_queued) return 1;
+    uint64_t c0 = 0, r0 = 0;
+    if ((rc = hsw_gadget_cell_position(g, 0, &c0, &r0)) != HSW_OK) die("cell_position", rc, eng);
+    if (o.row + 1 < v.max_rows && (c0 != o.column || r0 != o.row)) { fprintf(stderr, "%s: origin\n", name); return 1; }
     for (size_t i = 0; i < n; i++) {
         hsw_result_cells rc_;
         if ((rc = hsw_gadget_result_cells(g, i, &rc_)) != HSW_OK) die("hsw_gadget_result_cells", rc, eng);
@@ -78,13 +93,18 @@ int main(void) {
     /* TestCircuit, test_sha256_correct1 (lib.rs:497-527): "abc" and "" */
     const size_t s1[2] = {128, 128}, l1[2] = {3, 0};
     const uint8_t *m1[2] = {(const uint8_t *)"abc", (const uint8_t *)""};
-    if (check_circuit("TestCircuit", s1, 2, m1, l1, 3)) return 1;
+    const origin_t fresh = {0, 0, 0, 0};
+    if (check_circuit("TestCircuit", s1, 2, m1, l1, 3, fresh)) return 1;
+    /* the same two digests in a circuit that has already assigned 131,000 rows of FlexGate column 2, loaded the
+     * Context's zero cell and queued 77 lookups: the first column break falls inside the first prologue */
+    const origin_t later = {2, 131000, 77, 1};
+    if (check_circuit("TestCircuit at (2, 131000)", s1, 2, m1, l1, 4, later)) return 1;
     /* bench circuit (benches/digest.rs:93,102-109,129): one 56-byte message of 0x01 */
     uint8_t msg[56];
     memset(msg, 1, sizeof msg);
     const size_t s2[1] = {1024}, l2[1] = {56};
     const uint8_t *m2[1] = {msg};
-    if (check_circuit("bench circuit", s2, 1, m2, l2, 9)) return 1;
+    if (check_circuit("bench circuit", s2, 1, m2, l2, 9, fresh)) return 1;
     puts("ok");
     return 0;
 }

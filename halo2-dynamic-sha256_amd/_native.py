@@ -154,7 +154,9 @@ class GadgetView(C.Structure):
                 ("capacity_blocks", C.c_size_t), ("num_limb_sum", C.c_uint64), ("cur_hash_idx", C.c_size_t),
                 ("gate_cells", C.c_uint64), ("gate_capacity", C.c_uint64), ("d_lookup", C.c_void_p),
                 ("lookup_cells", C.c_uint64), ("lookup_capacity", C.c_uint64),
-                ("max_rows", C.c_uint64), ("columns", C.c_uint64)]
+                ("max_rows", C.c_uint64), ("columns", C.c_uint64),
+                ("origin_column", C.c_uint64), ("origin_row", C.c_uint64), ("origin_lookups", C.c_uint64),
+                ("origin_zero_loaded", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 # every symbol include/hsw.h declares (tests check the library exports them all)
@@ -173,6 +175,7 @@ SYMBOLS = (
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
     "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
     "hsw_gadget_download_region_compact", "hsw_region_widen", "hsw_gadget_result_cells",
+    "hsw_gadget_set_origin",
 )
 
 
@@ -286,6 +289,8 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_gadget_set_origin.restype = C.c_int
+        L.hsw_gadget_set_origin.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.hsw_verify_frames.restype = C.c_int
         L.hsw_verify_frames.argtypes = [vp, C.POINTER(FrameDesc), C.c_size_t, vp, vp, vp, vp, vp, C.POINTER(PackPlan),
                                         C.c_uint32, C.POINTER(VerifyReport)]

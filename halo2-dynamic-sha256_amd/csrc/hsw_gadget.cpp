@@ -213,9 +213,16 @@ Context::~Context() {
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
     (void)hipFree(d_init_states); (void)hipFree(d_offsets); (void)hipFree(d_lookup);
     if (hp_blocks) (void)hipHostFree(hp_blocks);
+    free_compact_staging();
+}
+
+void Context::free_compact_staging() {
     (void)hipFree(d_c_gate); (void)hipFree(d_c_lookup); (void)hipFree(d_c_dense); (void)hipFree(d_c_spread);
     (void)hipFree(d_wide); (void)hipFree(d_wide_count);
     if (hp_wide_count) (void)hipHostFree(hp_wide_count);
+    d_c_gate = d_c_lookup = d_c_dense = d_c_spread = d_wide = nullptr;
+    d_wide_count = hp_wide_count = nullptr;
+    wide_cap = 0;
 }
 
 int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
@@ -254,7 +261,7 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
             lookups += fs.digest_lookups;
         }
         c->gate_capacity = cells;
-        c->lookup_capacity = lookups;
+        c->lookup_capacity = c->own_lookup_capacity = lookups;
         gate_cells = (size_t)cells;
     }
     hipError_t he = hipMalloc(&c->d_gate, gate_cells * HSW_CELL_BYTES);
@@ -303,12 +310,13 @@ int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint6
     if (!whole || blocks_done != 0 || gate_cursor != 0) return HSW_ERR_INVALID_ARG;
     const uint64_t G = shape.gate_cells_per_block;
     if (rows < G + 16) return HSW_ERR_INVALID_ARG;        // keeps a block inside <= 2 columns (kernel: <= 2 breaks per block)
+    if (origin_row >= rows) return HSW_ERR_INVALID_ARG;   // the Context's next free row lies inside its column
     size_t n = 0;
     if (hsw_gate_tape(&shape, nullptr, 0, &n) != HSW_OK) return HSW_ERR_INVALID_ARG;
     std::vector<uint8_t> block_tape(n);
     hsw_gate_tape(&shape, block_tape.data(), n, nullptr);
     std::vector<uint64_t> bc, bg;
-    uint64_t row = 0, cell = 0;
+    uint64_t row = origin_row, cell = 0;                  // the Context's next free row (hsw_gadget_set_origin)
     auto walk = [&](const std::vector<uint8_t> &lens) {
         for (uint8_t len : lens) {
             if (row + len >= rows) {                      // halo2-lib v0.2.x assign_region: next column (A3-iii)
@@ -318,7 +326,7 @@ int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint6
             row += len; cell += len;
         }
     };
-    bool zero = false;
+    bool zero = origin_zero_loaded;                       // a Context that already caches its zero cell assigns none
     for (size_t b : sizes) {
         for (int section = 0; section < 2; section++) {
             if (section == 1) {
@@ -342,12 +350,14 @@ int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint6
     hsw_engine_stream(engine, nullptr, &device);
     DeviceScope ds2(device);
     if (!ds2.ok) return HSW_ERR_NO_DEVICE;
+    // (outstanding work on the old image: the callers -- hsw_gadget_set_columns / _set_origin -- run on a drained engine)
     void *img = nullptr;
     hipError_t he = hipMalloc(&img, (size_t)(cols * rows) * HSW_CELL_BYTES);
     if (he == hipSuccess) he = hipMemset(img, 0, (size_t)(cols * rows) * HSW_CELL_BYTES);   // unassigned advice cells are 0
     if (he != hipSuccess) { if (img) (void)hipFree(img); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
     (void)hipFree(d_gate);
     d_gate = img;
+    free_compact_staging();                               // sized for the old geometry
     max_rows = rows;
     columns = cols;
     break_cell.swap(bc);
@@ -356,11 +366,37 @@ int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint6
 }
 
 void Context::position(uint64_t cell, uint64_t *column, uint64_t *row) const {
-    uint64_t at = cell;
+    uint64_t at = cell + origin_row;
     for (size_t k = 0; k < break_cell.size(); k++)
         if (break_cell[k] <= cell) at += break_gap[k];
-    if (max_rows) { if (column) *column = at / max_rows; if (row) *row = at % max_rows; }
-    else { if (column) *column = 0; if (row) *row = at; }
+    if (max_rows) { if (column) *column = origin_column + at / max_rows; if (row) *row = at % max_rows; }
+    else { if (column) *column = origin_column; if (row) *row = at; }
+}
+
+int Context::set_origin(uint64_t column, uint64_t row, bool zero_cell_loaded, uint64_t lookups_queued) {
+    if (!whole || blocks_done != 0 || gate_cursor != 0 || lookup_cursor != origin_lookups) return HSW_ERR_INVALID_ARG;
+    if (max_rows && row >= max_rows) return HSW_ERR_INVALID_ARG;
+    if (lookups_queued != origin_lookups) {
+        // the lookup-advice stream is indexed from the Context's first queued cell: [0, lookups_queued) are the caller's
+        int device = 0;
+        hsw_engine_stream(engine, nullptr, &device);
+        DeviceScope ds(device);
+        if (!ds.ok) return HSW_ERR_NO_DEVICE;
+        const size_t lbytes = (size_t)(own_lookup_capacity + lookups_queued ? own_lookup_capacity + lookups_queued : 1) * HSW_CELL_BYTES;
+        void *lk = nullptr;
+        hipError_t he = hipMalloc(&lk, lbytes);
+        if (he == hipSuccess) he = hipMemset(lk, 0, lbytes);
+        if (he != hipSuccess) { if (lk) (void)hipFree(lk); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
+        (void)hipFree(d_lookup);
+        d_lookup = lk;
+        free_compact_staging();
+    }
+    origin_column = column; origin_row = row; origin_zero_loaded = zero_cell_loaded; origin_lookups = lookups_queued;
+    lookup_capacity = own_lookup_capacity + lookups_queued;
+    lookup_cursor = lookups_queued;
+    zero_loaded = zero_cell_loaded;
+    // without the zero cell the stream is one cell shorter
+    return HSW_OK;
 }
 
 int Sha256DynamicConfig::digest(Context &ctx, const uint8_t *input, size_t input_len,
@@ -527,7 +563,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                 a.d_pre_states = d_pre + 8 * ob;
                 a.n_blocks = run_blocks;
                 a.spread_cursor0 = cursor;
-                a.d_gate = static_cast<uint8_t *>(ctx.d_gate) + (size_t)results[i].block_cell * cb;
+                a.d_gate = static_cast<uint8_t *>(ctx.gate_stream()) + (size_t)results[i].block_cell * cb;
                 a.d_chip_dense = static_cast<uint8_t *>(ctx.d_chip_dense) + (size_t)row_shift * cb;
                 a.d_chip_spread = static_cast<uint8_t *>(ctx.d_chip_spread) + (size_t)row_shift * cb;
                 a.chip_col_stride = ctx.chip_col_stride;
@@ -553,7 +589,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                     da.blocks = a;
                     da.descs = frames.data() + i; da.n_digests = j - i;      // this run's digests: frames in the same launch
                     da.d_blocks0 = in_blocks; da.d_pre_states0 = in_pre; da.d_next_states0 = ctx.d_next_states;
-                    da.d_gate0 = ctx.d_gate; da.d_lookup0 = ctx.d_lookup;
+                    da.d_gate0 = ctx.gate_stream(); da.d_lookup0 = ctx.d_lookup;
                     hsw_pack_plan abs_plan{};
                     abs_plan.n_breaks = (uint32_t)ctx.break_cell.size();
                     for (size_t k = 0; k < ctx.break_cell.size(); k++) {
@@ -578,7 +614,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                     plan.break_gap[k] = ctx.break_gap[k];
                 }
                 rc = hsw_witness_frames(ctx.engine, frames.data(), n, in_blocks, in_pre, ctx.d_next_states,
-                                        ctx.d_gate, ctx.d_lookup, ctx.max_rows ? &plan : nullptr, ctx.repr_flags);
+                                        ctx.gate_stream(), ctx.d_lookup, ctx.max_rows ? &plan : nullptr, ctx.repr_flags);
             }
             if (rc == HSW_OK) { new_gate_cursor = gc; new_lookup_cursor = lc; }
         }
@@ -734,6 +770,11 @@ int hsw_gadget_streams(hsw_gadget *g, hsw_gadget_view *view) try {
     view->lookup_capacity = g->ctx->lookup_capacity;
     view->max_rows = g->ctx->max_rows;
     view->columns = g->ctx->columns;
+    view->origin_column = g->ctx->origin_column;
+    view->origin_row = g->ctx->origin_row;
+    view->origin_lookups = g->ctx->origin_lookups;
+    view->origin_zero_loaded = g->ctx->origin_zero_loaded ? 1u : 0u;
+    view->reserved_ = 0;
     return HSW_OK;
 } HSW_NO_UNWIND
 
@@ -770,9 +811,31 @@ int hsw_gadget_result_cells(const hsw_gadget *g, size_t hash_idx, hsw_result_cel
 
 int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns) try {
     if (!g) return HSW_ERR_INVALID_ARG;
-    const int rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
+    int rc = hsw_engine_synchronize(g->ctx->engine);          // the image is reallocated: nothing may still write the old one
+    if (rc == HSW_OK) rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
     if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
     return rc;
+} HSW_NO_UNWIND
+
+int hsw_gadget_set_origin(hsw_gadget *g, uint64_t column, uint64_t row, int zero_cell_loaded,
+                          uint64_t lookups_already_queued) try {
+    if (!g) return HSW_ERR_INVALID_ARG;
+    hsw::Context &c = *g->ctx;
+    if (!c.whole || g->cfg.cur_hash_idx != 0) return HSW_ERR_INVALID_ARG;   // before the first digest of a synthesis pass
+    int rc = hsw_engine_synchronize(c.engine);
+    if (rc != HSW_OK) return rc;
+    const uint64_t old[4] = {c.origin_column, c.origin_row, c.origin_zero_loaded ? 1u : 0u, c.origin_lookups};
+    rc = c.set_origin(column, row, zero_cell_loaded != 0, lookups_already_queued);
+    if (rc != HSW_OK) return rc;
+    if (c.max_rows && (old[1] != row || old[2] != (zero_cell_loaded ? 1u : 0u))) {
+        // the column breaks follow from where the stream starts: lay the image out again
+        rc = c.set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, c.max_rows);
+        if (rc != HSW_OK) {                                      // e.g. one column too many now: keep the old layout
+            (void)c.set_origin(old[0], old[1], old[2] != 0, old[3]);
+            return rc;
+        }
+    }
+    return HSW_OK;
 } HSW_NO_UNWIND
 
 int hsw_gadget_reset(hsw_gadget *g) try {
@@ -782,8 +845,9 @@ int hsw_gadget_reset(hsw_gadget *g) try {
     hsw::Context &c = *g->ctx;
     c.blocks_done = 0;
     c.num_limb_sum = 0;                 // spread.rs:70-71
-    c.gate_cursor = c.lookup_cursor = 0;
-    c.zero_loaded = false;
+    c.gate_cursor = 0;
+    c.lookup_cursor = c.origin_lookups; // the Context as the caller hands it over (hsw_gadget_set_origin)
+    c.zero_loaded = c.origin_zero_loaded;
     c.batches.clear();
     g->cfg.cur_hash_idx = 0;            // lib.rs:66
     g->results.clear();
@@ -810,16 +874,19 @@ int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) try {
             // used rows of column k: up to its break (max_rows - gap), the last column up to the cursor
             uint64_t last_col = 0, last_row = 0;
             if (c.gate_cursor) { c.position(c.gate_cursor - 1, &last_col, &last_row); last_row += 1; }
+            last_col -= c.origin_column;                              // image column
             for (uint64_t k = 0; k <= last_col && c.gate_cursor; k++) {
                 const uint64_t used = k < last_col ? c.max_rows - c.break_gap[k] : last_row;
-                copy(dst->gate, c.d_gate, (size_t)(k * c.max_rows), (size_t)used);
+                const uint64_t first = k == 0 ? c.origin_row : 0;    // rows above the origin are the caller's
+                if (used > first) copy(dst->gate, c.d_gate, (size_t)(k * c.max_rows + first), (size_t)(used - first));
             }
         } else {
             const size_t cells = c.whole ? (size_t)c.gate_cursor : c.blocks_done * (size_t)c.shape.gate_cells_per_block;
             copy(dst->gate, c.d_gate, 0, cells);
         }
     }
-    if (dst->lookup && c.d_lookup) copy(dst->lookup, c.d_lookup, 0, (size_t)c.lookup_cursor);
+    if (dst->lookup && c.d_lookup)
+        copy(dst->lookup, c.d_lookup, (size_t)c.origin_lookups, (size_t)(c.lookup_cursor - c.origin_lookups));
     const uint32_t ncols = c.shape.num_advice_columns;
     const size_t rows = (size_t)((c.num_limb_sum + ncols - 1) / ncols);
     for (uint32_t k = 0; k < ncols; k++) {
@@ -845,7 +912,8 @@ int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst) t
     const size_t gate_cells = c.whole ? (c.max_rows ? (size_t)(c.max_rows * (c.break_cell.size() + 1)) : (size_t)c.gate_capacity)
                                       : c.capacity_blocks * (size_t)c.shape.gate_cells_per_block;
     hipError_t he = hipSuccess;
-    if (!c.d_wide) {        // first use: the 8-byte staging of every stream, the side list and its counter
+    if (!c.d_wide) {        // first use (or the geometry changed: set_columns / set_origin drop the staging):
+                            // the 8-byte staging of every stream, the side list and its counter
         // wide cells: 4 ch negations per round (256 per block) + a few dozen per digest frame
         c.wide_cap = c.capacity_blocks * 256 + 128 * (c.init_capacity + 1) + 4 * c.capacity_blocks + 64;
         he = hipMalloc(&c.d_c_gate, (gate_cells ? gate_cells : 1) * 8);
@@ -855,7 +923,7 @@ int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst) t
         if (he == hipSuccess) he = hipMalloc((void **)&c.d_wide_count, sizeof(uint32_t));
         if (he == hipSuccess) he = hipHostMalloc((void **)&c.hp_wide_count, sizeof(uint32_t), hipHostMallocDefault);
         if (he == hipSuccess) he = hipMalloc(&c.d_wide, c.wide_cap * 48);
-        if (he != hipSuccess) return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP;
+        if (he != hipSuccess) { c.free_compact_staging(); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
     }
     he = hipMemsetAsync(c.d_wide_count, 0, sizeof(uint32_t), stream);
     auto pack = [&](uint64_t *h, void *d8, const void *d32, uint64_t sid, size_t cell0, size_t cells) {
@@ -870,13 +938,16 @@ int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst) t
         // the end of every column are zero on the device and travel as zeros (a launch and a copy per column
         // would cost more than the bytes they save)
         uint64_t last_col = 0, last_row = 0;
-        if (c.gate_cursor) { c.position(c.gate_cursor - 1, &last_col, &last_row); last_row += 1; }
-        pack(dst->gate, c.d_c_gate, c.d_gate, HSW_STREAM_GATE, 0, c.gate_cursor ? (size_t)(last_col * c.max_rows + last_row) : 0);
+        if (c.gate_cursor) { c.position(c.gate_cursor - 1, &last_col, &last_row); last_row += 1; last_col -= c.origin_column; }
+        // (from the origin row on: the rows above it in image column 0 are the caller's cells)
+        pack(dst->gate, c.d_c_gate, c.d_gate, HSW_STREAM_GATE, (size_t)c.origin_row,
+             c.gate_cursor ? (size_t)(last_col * c.max_rows + last_row - c.origin_row) : 0);
     } else {
         pack(dst->gate, c.d_c_gate, c.d_gate, HSW_STREAM_GATE, 0,
              c.whole ? (size_t)c.gate_cursor : c.blocks_done * (size_t)c.shape.gate_cells_per_block);
     }
-    if (c.d_lookup) pack(dst->lookup, c.d_c_lookup, c.d_lookup, HSW_STREAM_LOOKUP, 0, (size_t)c.lookup_cursor);
+    if (c.d_lookup)
+        pack(dst->lookup, c.d_c_lookup, c.d_lookup, HSW_STREAM_LOOKUP, (size_t)c.origin_lookups, (size_t)(c.lookup_cursor - c.origin_lookups));
     const size_t rows = (size_t)((c.num_limb_sum + ncols - 1) / ncols);
     if (rows == c.chip_col_stride) {         // every column full: one pass per family
         pack(dst->chip_dense, c.d_c_dense, c.d_chip_dense, HSW_STREAM_CHIP_DENSE, 0, rows * ncols);
@@ -918,7 +989,7 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {
     if (rc != HSW_OK) return rc;
     hsw::Context &c = *g->ctx;
     size_t blocks = 0;
-    uint64_t gate = 0, lookup = 0;
+    uint64_t gate = 0, lookup = c.origin_lookups;
     for (size_t h = 0; h < hash_idx; h++) {
         const size_t b = g->cfg.max_variable_byte_sizes[h];
         blocks += b / 64;
@@ -926,7 +997,7 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {
             hsw_frame_shape fs;
             rc = hsw_frame_query(&c.shape, b, g->cfg.is_input_range_check ? 1 : 0, &fs);
             if (rc != HSW_OK) return rc;
-            gate += fs.digest_cells + (h == 0 ? 1 : 0);       // + the Context's zero cell, loaded by digest #0
+            gate += fs.digest_cells + (h == 0 && !c.origin_zero_loaded ? 1 : 0);   // + the Context's zero cell, loaded by digest #0
             lookup += fs.digest_lookups;
         }
     }
@@ -934,7 +1005,7 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {
     c.num_limb_sum = (uint64_t)blocks * c.shape.limb_calls_per_block;       // spread.rs:228-231
     c.gate_cursor = gate;
     c.lookup_cursor = lookup;
-    c.zero_loaded = hash_idx > 0;
+    c.zero_loaded = c.origin_zero_loaded || hash_idx > 0;
     g->cfg.cur_hash_idx = hash_idx;
     c.batches.clear();
     g->results.clear();
@@ -991,7 +1062,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) try {
             a.d_blocks = in_blocks + 64 * fb; a.d_pre_states = in_pre + 8 * fb; a.n_blocks = run_blocks;
             a.spread_cursor0 = (uint64_t)fb * c.shape.limb_calls_per_block;
             const uint64_t row_shift = a.spread_cursor0 / ncols;
-            a.d_gate = static_cast<uint8_t *>(c.d_gate) + (size_t)r0.block_cell * cb;
+            a.d_gate = static_cast<uint8_t *>(c.gate_stream()) + (size_t)r0.block_cell * cb;
             a.d_chip_dense = static_cast<uint8_t *>(c.d_chip_dense) + (size_t)row_shift * cb;
             a.d_chip_spread = static_cast<uint8_t *>(c.d_chip_spread) + (size_t)row_shift * cb;
             a.chip_col_stride = c.chip_col_stride;
@@ -1026,7 +1097,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) try {
                 d.zero_cell = rk.block_cell == rk.prologue_cell + fs.prologue_cells + 1 ? rk.block_cell - 1 : ~0ull;
                 blk += rk.n_blocks;
             }
-            rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), in_blocks, in_pre, c.d_next_states, c.d_gate,
+            rc = hsw_verify_frames(c.engine, descs.data(), descs.size(), in_blocks, in_pre, c.d_next_states, c.gate_stream(),
                                    c.d_lookup, c.max_rows ? &abs_plan : nullptr, b.repr_flags, &r);
             if (rc != HSW_OK) return rc;
             merge(r);

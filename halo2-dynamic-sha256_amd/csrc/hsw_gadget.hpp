@@ -132,11 +132,27 @@ class Context {
     // stream cell i sits at i + the gaps of all breaks at or before i (assumption A3-iii)
     uint64_t max_rows = 0, columns = 0;
     std::vector<uint64_t> break_cell, break_gap;
+    // Where the caller's halo2-base Context stood when it handed the region to the gadget (hsw_gadget_set_origin;
+    // the reference's digest takes whatever Context it is given, lib.rs:71-76,351-360): stream cell 0 lands at
+    // (origin_column, origin_row) = ctx.advice_alloc[0]; the Context may already cache its zero cell
+    // (ctx.zero_cell, A4-iii: then no digest of this gadget assigns one) and may have queued
+    // origin_lookups cells for the lookup-advice column (ctx.cells_to_lookup.len()).  With a column image,
+    // image column k is FlexGate column origin_column + k and rows [0, origin_row) of image column 0 are
+    // the caller's: never written, never delivered.
+    uint64_t origin_column = 0, origin_row = 0, origin_lookups = 0;
+    bool origin_zero_loaded = false;
+    uint64_t own_lookup_capacity = 0;                  // lookup_capacity - origin_lookups
+    int set_origin(uint64_t column, uint64_t row, bool zero_cell_loaded, uint64_t lookups_queued);
+    // device address of stream cell 0 (32-byte cells: whole-digest contexts have no compact form)
+    void *gate_stream() const {
+        return static_cast<uint8_t *>(d_gate) + (size_t)(max_rows ? origin_row : 0) * HSW_CELL_BYTES;
+    }
     // Lay the whole-digest stream out as FlexGate (Vertical) advice columns of max_rows usable rows.
     // Only before the first digest.  HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns.
     int set_columns(const std::vector<size_t> &max_variable_byte_sizes, bool is_input_range_check, uint64_t max_rows);
     // (column, row) of stream cell i
     void position(uint64_t cell, uint64_t *column, uint64_t *row) const;
+    void free_compact_staging();                       // the 8-byte staging follows the geometry: dropped when it changes
 };
 
 }  // namespace hsw

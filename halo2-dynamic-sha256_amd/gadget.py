@@ -108,6 +108,11 @@ class Sha256DynamicConfig:
         self._ok(self.lib.hsw_gadget_set_columns(self.h, max_rows, C.byref(n)))
         return int(n.value)
 
+    def set_origin(self, column=0, row=0, zero_cell_loaded=False, lookups_queued=0):
+        """Where the caller's halo2-base Context stands when the gadget takes over (hsw_gadget_set_origin):
+        ctx.advice_alloc[0] = (column, row), ctx.zero_cell.is_some(), ctx.cells_to_lookup.len()."""
+        self._ok(self.lib.hsw_gadget_set_origin(self.h, column, row, 1 if zero_cell_loaded else 0, lookups_queued))
+
     def reset(self):
         """Next synthesis pass: all cursors back to their start, buffers and layout kept
         (the reference clones the config per synthesis, lib.rs:440)."""

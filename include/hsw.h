@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define HSW_ABI_VERSION 2
+#define HSW_ABI_VERSION 3   /* 3: hsw_gadget_view grew the origin fields; hsw_gadget_set_origin */
 
 /* ---- status codes ---- */
 #define HSW_OK                 0
@@ -72,7 +72,8 @@ extern "C" {
 #define HSW_SKIP_GATE          2u  /* do not write the gate stream (d_gate may be NULL) */
 #define HSW_SKIP_CHIP          4u  /* do not write the chip columns (pointers may be NULL) */
 
-#define HSW_HOST_REGISTER       8u  /* hsw_witness_blocks_host only.  Accepted and IGNORED since round 2: the library
+#define HSW_HOST_REGISTER       8u  /* DEPRECATED (to be removed at the next ABI version).  hsw_witness_blocks_host only.
+                                      Accepted and IGNORED since ABI 2: the library
                                       never pins memory it does not own (hipHostRegister on a caller's heap buffers
                                       ended in GPU memory faults twice: a user-pointer registration does not survive
                                       the allocator trimming and re-growing its heap).  Pageable buffers take the
@@ -506,6 +507,11 @@ typedef struct hsw_gadget_view {
     void *d_lookup;
     uint64_t lookup_cells, lookup_capacity;
     uint64_t max_rows, columns;         /* hsw_gadget_set_columns: d_gate is columns x max_rows cells; else 0 */
+    /* hsw_gadget_set_origin (all 0 by default): image column k is FlexGate column origin_column + k, stream
+     * cell 0 sits at row origin_row of image column 0, the gadget's lookup entries start at d_lookup cell
+     * origin_lookups (lookup_cells / lookup_capacity count from cell 0 of the buffer) */
+    uint64_t origin_column, origin_row, origin_lookups;
+    uint32_t origin_zero_loaded, reserved_;
 } hsw_gadget_view;
 
 /* Sha256DynamicConfig::configure (lib.rs:49-69) + new_context (lib.rs:351-360):
@@ -527,6 +533,30 @@ void hsw_gadget_destroy(hsw_gadget *g);
  * layout depends only on max_variable_byte_sizes, never on the messages.
  * HSW_ERR_TOO_LARGE: more than HSW_MAX_BREAKS + 1 columns. */
 int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns);
+/* HSW_GADGET_WHOLE_DIGEST, before the first digest of a synthesis pass (fresh, or after hsw_gadget_reset;
+ * before or after hsw_gadget_set_columns): where the caller's halo2-base Context stands when it hands
+ * the region to the gadget.  The reference's digest() works on whatever Context it is given
+ * (lib.rs:71-76, 351-360) -- a circuit that has used the gate / range chips before its first digest is
+ * the normal case outside the reference's two harnesses.
+ *   column, row              ctx.advice_alloc[0]: the FlexGate column in use and its next free row.
+ *                            Stream cell 0 lands there and the column breaks follow from it (A3-iii);
+ *                            with a column image, image column k = FlexGate column `column + k`, rows
+ *                            [0, row) of image column 0 belong to the caller: they are never written by
+ *                            the gadget and never touched in the caller's host buffers by the downloads.
+ *                            hsw_gadget_cell_position / hsw_gadget_result_cells report FlexGate columns.
+ *   zero_cell_loaded         ctx.zero_cell.is_some(): the Context already caches its [Constant(0)] cell
+ *                            (A4-iii), so no digest of this gadget assigns one -- the stream is one cell
+ *                            shorter and hsw_frame_desc.zero_cell is never set.
+ *   lookups_already_queued   ctx.cells_to_lookup.len(): RangeConfig::finalize (lib.rs:469) copies the queue
+ *                            into the lookup-advice column in order, so the gadget's entries start at that
+ *                            index: d_lookup is reallocated with that many leading cells (zero, the
+ *                            caller's), every *_lookup index of hsw_hash_result counts from cell 0.
+ * The origin survives hsw_gadget_reset (the next synthesis of the same circuit starts at the same place).
+ * HSW_ERR_INVALID_ARG: not a whole-digest context, digests already assigned in this pass, or row >= max_rows;
+ * HSW_ERR_TOO_LARGE: the layout from that row needs more than HSW_MAX_BREAKS + 1 columns (the previous
+ * origin and layout are kept). */
+int hsw_gadget_set_origin(hsw_gadget *g, uint64_t column, uint64_t row, int zero_cell_loaded,
+                          uint64_t lookups_already_queued);
 /* Start the next synthesis pass with the same buffers and layout: every cursor back to
  * its initial value (cur_hash_idx, num_limb_sum, the stream cursors, the Context's zero
  * cell).  What the reference's harnesses do by cloning the config per synthesis

@@ -1094,6 +1094,10 @@ int oracle_digest_cells(oracle_ctx *c, const uint8_t *input, size_t input_byte_s
     free(padded_inputs); free(assigned_input_bytes); free(states);
     return c->failed ? 1 : 0;
 }
+void oracle_set_context(oracle_ctx *c, int zero_cell_loaded) {
+    c->zero_loaded = zero_cell_loaded != 0;
+    c->zero_cell = ORACLE_CELL_ZERO;
+}
 void oracle_set_tape(oracle_ctx *c, uint8_t *call_lens, size_t call_cap, uint64_t *gate_rows, size_t rows_cap) {
     c->call_lens = call_lens; c->call_cap = call_cap; c->n_calls = 0;
     c->gate_rows = gate_rows; c->rows_cap = rows_cap; c->n_rows = 0;

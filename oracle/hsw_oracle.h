@@ -179,6 +179,13 @@ typedef struct {
 int oracle_digest_cells(oracle_ctx *c, const uint8_t *input, size_t input_len,
                         size_t precomputed_input_len, size_t max_variable_byte_size,
                         int is_input_range_check, uint8_t digest[32], oracle_digest_layout_t *lay);
+/* The state of the halo2-base Context the next oracle_digest_cells call is handed (the reference's
+ * digest() takes whatever Context it is given, lib.rs:71-76,351-360): zero_cell_loaded != 0 = the Context
+ * already caches its [Constant(0)] cell (ctx.zero_cell.is_some(), A4-iii), so no digest assigns one -- its
+ * cell id is then ORACLE_CELL_ZERO (outside the stream).  Where the first cell lands
+ * (ctx.advice_alloc[0]) and how many cells are already queued for the lookup column only shift positions:
+ * the tests apply them to the tape / lookup stream this oracle returns. */
+void oracle_set_context(oracle_ctx *c, int zero_cell_loaded);
 /* Optional recorders of the halo2-base call structure: the length of every
  * assign_region call (the replay tape) and the stream index of every enabled
  * gate row (x0 + x1*x2 = x3 on cells [i, i+3]).  Reset by this call. */

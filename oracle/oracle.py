@@ -107,6 +107,7 @@ def lib():
         L.oracle_digest_cells.restype = C.c_int
         L.oracle_digest_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
                                           C.c_void_p, C.POINTER(DigestLayout)]
+        L.oracle_set_context.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.oracle_tape_calls.restype = C.c_size_t
         L.oracle_tape_calls.argtypes = [C.c_void_p]
@@ -262,8 +263,9 @@ class Oracle:
 
 
 def digest_cells(messages, max_sizes, precomputed=None, is_input_range_check=False, record=False,
-                 num_bits_lookup=8, num_advice_columns=2):
-    """len(messages) consecutive Sha256DynamicConfig::digest calls in ONE fresh Context
+                 num_bits_lookup=8, num_advice_columns=2, zero_cell_loaded=False):
+    """len(messages) consecutive Sha256DynamicConfig::digest calls in ONE Context -- fresh, or
+    (zero_cell_loaded) one that already caches its zero cell, as after other halo2-base calls --
     (the reference's TestCircuit makes two, lib.rs:455-466) with every cell digest()
     allocates, under assumptions A1-A4 (hsw_oracle.h: oracle_digest_cells).
     Returns dict: gate (N,4) u64, lookup (M,4) u64, dense/spread (ncols, rows, 4), digests,
@@ -290,6 +292,8 @@ def digest_cells(messages, max_sizes, precomputed=None, is_input_range_check=Fal
     L.oracle_set_outputs(o.h, gate.ctypes.data, gcap, dense.ctypes.data, spread.ctypes.data, dense.shape[1], 0)
     L.oracle_set_lookup_output(o.h, lookup.ctypes.data, lcap)
     L.oracle_set_tape(o.h, call_lens.ctypes.data, gcap, gate_rows.ctypes.data, gcap)
+    if zero_cell_loaded:
+        L.oracle_set_context(o.h, 1)
     cs = None
     if record:
         cap = gcap

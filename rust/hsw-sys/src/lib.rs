@@ -295,6 +295,11 @@ pub struct hsw_gadget_view {
     pub lookup_capacity: u64,
     pub max_rows: u64,
     pub columns: u64,
+    pub origin_column: u64,
+    pub origin_row: u64,
+    pub origin_lookups: u64,
+    pub origin_zero_loaded: u32,
+    pub reserved_: u32,
 }
 
 extern "C" {
@@ -353,6 +358,9 @@ extern "C" {
                                 is_input_range_check: c_int, flags: u32, out: *mut *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
+    /// Where the caller's `Context` stands: `ctx.advice_alloc[0]`, `ctx.zero_cell.is_some()`, `ctx.cells_to_lookup.len()`.
+    pub fn hsw_gadget_set_origin(g: *mut hsw_gadget, column: u64, row: u64, zero_cell_loaded: c_int,
+                                 lookups_already_queued: u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
     pub fn hsw_verify_frames(e: *mut hsw_engine, descs: *const hsw_frame_desc, n: usize, d_blocks: *const u8,

@@ -11,12 +11,23 @@
 //! ```ignore
 //! pub fn digest<'a, 'b: 'a>(&'a mut self, ctx: &mut Context<'b, F>, input: &'a [u8],
 //!                           precomputed_input_len: Option<usize>) -> Result<AssignedHashResult<F>, Error> {
-//!     if hsw::witness_only_pass(ctx, self)? {
-//!         return hsw::digest_gpu(self, ctx, input, precomputed_input_len);      // this file
+//!     if hsw::witness_only_pass(ctx, self) {
+//!         if let Some(r) = hsw::digest_gpu(self, ctx, input, precomputed_input_len)? { return Ok(r); }   // this file
 //!     }
 //!     self.digest_cpu(ctx, input, precomputed_input_len)                          // the reference's body, unchanged
 //! }
 //! ```
+//!
+//! `digest_gpu` NEVER turns a circuit that works on the CPU into an error: whatever the C side refuses (no device,
+//! a layout with more than 17 columns, a `Context` that moved between two digests, ...) makes it return `Ok(None)`
+//! before it has touched `ctx`, and `digest` runs the reference's own body.  Only errors of `Region::assign_advice`
+//! itself propagate.
+//!
+//! WHERE the region starts.  The reference's `digest` takes whatever `Context` it is handed (lib.rs:71-76,
+//! 351-360): a circuit that has used the gate / range chips before its first digest stands at
+//! `ctx.advice_alloc[0] = (column, row) != (0, 0)`, usually caches a zero cell (`ctx.zero_cell`) and has cells
+//! queued for the lookup column (`ctx.cells_to_lookup`).  All three go to `hsw_gadget_set_origin`; the GPU lays the
+//! region out from there (column breaks included) exactly as `FlexGateConfig::assign_region` would.
 //!
 //! WHEN the GPU path may run.  Selectors, fixed cells and copy constraints do not depend on the witness;
 //! halo2 records them during key generation (`keygen_vk` / `keygen_pk`) and `MockProver::run` checks them.
@@ -26,11 +37,14 @@
 //! `witness_only_pass` tells the passes apart from inside the gadget (ASSUMPTION A5, halo2_proofs PSE
 //! v2023_02_02 `plonk/keygen.rs`, `plonk/prover.rs`, `dev.rs`; unpinned like A1-A4):
 //!
-//! | backend            | `assign_advice` closure | `assign_fixed` closure | => value known? (advice, fixed) |
-//! |--------------------|-------------------------|------------------------|---------------------------------|
-//! | keygen `Assembly`  | not called              | called                 | (no, yes)  -> CPU                |
-//! | `MockProver`       | called                  | called                 | (yes, yes) -> CPU                |
-//! | `WitnessCollection`| called                  | not called             | (yes, no)  -> GPU                |
+//! | backend            | `assign_fixed(.., || Value::unknown())`                       | =>  |
+//! |--------------------|----------------------------------------------------------------|-----|
+//! | keygen `Assembly`  | evaluates the closure: `Err(Synthesis)`, nothing stored        | CPU |
+//! | `MockProver`       | evaluates the closure: `Err(Synthesis)`, nothing stored        | CPU |
+//! | `WitnessCollection`| ignores fixed assignments: `Ok(())`                            | GPU |
+//!
+//! The probe writes NOTHING in any backend (round 2 probed with real assignments of 0: a fixed cell another region
+//! had already finalised a constant into would have been zeroed in the proving key).
 //!
 //! `hsw::force(Some(bool))` overrides the detection (a process-wide switch for a prover driver that prefers to
 //! say so itself); `HSW_DISABLE=1` in the environment pins the CPU path.
@@ -52,6 +66,16 @@ fn check(rc: i32) -> Result<(), Error> {
     if rc == sys::HSW_OK { Ok(()) } else { Err(Error::Synthesis) }
 }
 
+/// Everything the C side hands over for one digest, fetched BEFORE `ctx` is touched: if any call fails the CPU
+/// path can still run on an untouched Context.
+struct Fetched {
+    r: sys::hsw_hash_result,
+    rc: sys::hsw_result_cells,
+    view: sys::hsw_gadget_view,
+    segs: Vec<(u64, u64, usize)>,          // (FlexGate column, first row, cells) of this digest's gate cells, in stream order
+    end: (u64, u64),                       // (column, row) of the digest's last cell
+}
+
 static FORCE: AtomicI8 = AtomicI8::new(-1);          // -1 = detect, 0 = CPU, 1 = GPU
 
 /// Override the pass detection for the whole process (`None` = detect again).
@@ -59,22 +83,14 @@ pub fn force(gpu: Option<bool>) {
     FORCE.store(match gpu { None => -1, Some(false) => 0, Some(true) => 1 }, Ordering::SeqCst);
 }
 
-/// Is this synthesis pass `create_proof`'s witness collection (A5 above)?  Probes with two assignments that
-/// change nothing: advice cell (gate column 0, row 0) is assigned by `digest` itself right afterwards
-/// (`load_witness(input_byte_size)`, lib.rs:124-125, is the first cell of the region when the gadget opens it;
-/// otherwise the probe goes to the next free row, `ctx.advice_alloc[0][0].1`, which is also assigned next), and
-/// the fixed cell gets 0, what an unassigned fixed cell holds (and what `finalize` overwrites if it needs the row).
-pub fn witness_only_pass<F: PrimeField>(ctx: &mut Context<'_, F>, sha256: &Sha256DynamicConfig<F>) -> Result<bool, Error> {
-    if std::env::var_os("HSW_DISABLE").is_some() { return Ok(false); }
-    match FORCE.load(Ordering::SeqCst) { 0 => return Ok(false), 1 => return Ok(true), _ => {} }
-    let gate = &sha256.range().gate;
-    let (col, row) = ctx.advice_alloc[0];                                 // (column index, next free row) of context 0
-    let adv: Column<Advice> = gate.basic_gates[0][col].value;
-    let fix: Column<Fixed> = gate.constants[0];
-    let a = ctx.region.assign_advice(|| "hsw probe", adv, row, || Value::known(F::zero()))?;
-    let f = ctx.region.assign_fixed(|| "hsw probe", fix, 0, || Value::known(F::zero()))?;
-    let known = |v: Value<&F>| { let mut k = false; v.map(|_| k = true); k };
-    Ok(known(a.value()) && !known(f.value()))
+/// Is this synthesis pass `create_proof`'s witness collection (A5 above)?  One `assign_fixed` of an UNKNOWN value:
+/// the backends that store fixed cells evaluate the closure and fail on it without storing anything; the witness
+/// pass ignores fixed assignments and returns `Ok`.  No cell of any column is written by the probe.
+pub fn witness_only_pass<F: PrimeField>(ctx: &mut Context<'_, F>, sha256: &Sha256DynamicConfig<F>) -> bool {
+    if std::env::var_os("HSW_DISABLE").is_some() { return false; }
+    match FORCE.load(Ordering::SeqCst) { 0 => return false, 1 => return true, _ => {} }
+    let fix: Column<Fixed> = sha256.range().gate.constants[0];
+    ctx.region.assign_fixed(|| "hsw probe", fix, 0, || Value::<F>::unknown()).is_ok()
 }
 
 /// One engine + one whole-digest gadget per (prover thread, circuit shape), reused by every synthesis.
@@ -82,6 +98,9 @@ struct Backend {
     engine: *mut sys::hsw_engine,
     gadget: *mut sys::hsw_gadget,
     key: (Vec<usize>, usize, usize, bool, u64),       // max sizes, table bits, chip columns, range checks, max_rows
+    // where the Context must stand for the gadget's NEXT digest of this pass: (advice_alloc[0], cells_to_lookup.len())
+    // as the previous digest left them; None = the pass is not (or no longer) on the GPU
+    expect: Option<((usize, usize), usize)>,
     max_rows: u64,
     chip_columns: usize,
     chip_col_stride: usize,
@@ -95,30 +114,35 @@ thread_local! { static BACKEND: RefCell<Option<Backend>> = RefCell::new(None); }
 impl Backend {
     fn new<F: PrimeField>(sha256: &Sha256DynamicConfig<F>, key: (Vec<usize>, usize, usize, bool, u64)) -> Result<Self, Error> {
         let device = std::env::var("HSW_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-        let mut engine = ptr::null_mut();
-        check(unsafe { sys::hsw_engine_create_ex(device, ptr::null_mut(), key.1 as u32, key.2 as u32,
-                                                 sys::HSW_MODE_HALO2_INTERNALS, &mut engine) })?;
-        let mut gadget = ptr::null_mut();
-        check(unsafe { sys::hsw_gadget_create_ex(engine, key.0.as_ptr(), key.0.len(), key.3 as i32,
-                                                 sys::HSW_GADGET_WHOLE_DIGEST, &mut gadget) })?;
+        // `be` owns whatever exists so far: an early `?` drops it and Drop releases engine / gadget / staging
+        let mut be = Self { engine: ptr::null_mut(), gadget: ptr::null_mut(), key, expect: None, max_rows: 0,
+                            chip_columns: sha256.spread_config.num_advice_columns, chip_col_stride: 0,
+                            stage: ptr::null_mut(), stage_cells: 0 };
+        check(unsafe { sys::hsw_engine_create_ex(device, ptr::null_mut(), be.key.1 as u32, be.key.2 as u32,
+                                                 sys::HSW_MODE_HALO2_INTERNALS, &mut be.engine) })?;
+        check(unsafe { sys::hsw_gadget_create_ex(be.engine, be.key.0.as_ptr(), be.key.0.len(), be.key.3 as i32,
+                                                 sys::HSW_GADGET_WHOLE_DIGEST, &mut be.gadget) })?;
         // halo2curves' in-memory Fr IS the cell format: no from_repr (a Montgomery multiplication) per cell
-        check(unsafe { sys::hsw_gadget_set_repr(gadget, sys::HSW_REPR_MONTGOMERY) })?;
+        check(unsafe { sys::hsw_gadget_set_repr(be.gadget, sys::HSW_REPR_MONTGOMERY) })?;
+        // the column image from (0, 0); every synthesis pass re-bases it on where its Context stands (set_origin)
         let mut columns = 0u64;
-        check(unsafe { sys::hsw_gadget_set_columns(gadget, key.4, &mut columns) })?;
-        if (columns as usize) > sha256.range().gate.basic_gates[0].len() { return Err(Error::Synthesis); }   // NUM_ADVICE too small
+        check(unsafe { sys::hsw_gadget_set_columns(be.gadget, be.key.4, &mut columns) })?;
         let mut view = unsafe { std::mem::zeroed::<sys::hsw_gadget_view>() };
-        check(unsafe { sys::hsw_gadget_streams(gadget, &mut view) })?;
-        let biggest = key.0.iter().copied().max().unwrap_or(64) / 64;
-        let stage_cells = biggest * 70_000 + 8 * biggest * 64 + 4096;          // a digest's gate cells (69,348 per block + frame)
+        check(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
+        be.max_rows = view.max_rows;
+        be.chip_col_stride = view.chip_col_stride;
+        let biggest = be.key.0.iter().copied().max().unwrap_or(64) / 64;
+        be.stage_cells = biggest * 70_000 + 8 * biggest * 64 + 4096;           // a digest's gate cells (69,348 per block + frame)
         let mut p: *mut c_void = ptr::null_mut();
-        check(unsafe { sys::hsw_host_alloc(stage_cells * 32, &mut p) })?;
-        Ok(Self { engine, gadget, key, max_rows: view.max_rows, chip_columns: sha256.spread_config.num_advice_columns,
-                  chip_col_stride: view.chip_col_stride, stage: p as *mut [u64; 4], stage_cells })
+        check(unsafe { sys::hsw_host_alloc(be.stage_cells * 32, &mut p) })?;
+        be.stage = p as *mut [u64; 4];
+        Ok(be)
     }
 }
 
 impl Drop for Backend {
     fn drop(&mut self) {
+        // (all three accept NULL)
         unsafe { sys::hsw_host_free(self.stage as *mut c_void); sys::hsw_gadget_destroy(self.gadget); sys::hsw_engine_destroy(self.engine); }
     }
 }
@@ -132,40 +156,27 @@ fn fe<F: PrimeField>(cell: &[u64; 4]) -> F {
 }
 
 /// `Sha256DynamicConfig::digest` with every advice cell taken from the GPU.  Same cells, same positions as
-/// the CPU path under A1-A4; returns the same `AssignedHashResult`.
+/// the CPU path under A1-A4; returns the same `AssignedHashResult`.  `Ok(None)` = the GPU path does not apply
+/// (or the C side refused): nothing has been touched, the caller runs `digest_cpu`.
 pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig<F>, ctx: &mut Context<'b, F>, input: &'a [u8],
-                                             precomputed_input_len: Option<usize>) -> Result<AssignedHashResult<F>, Error> {
+                                             precomputed_input_len: Option<usize>) -> Result<Option<AssignedHashResult<F>>, Error> {
     let key = (sha256.max_variable_byte_sizes.clone(), sha256.spread_config.num_bits_lookup, sha256.spread_config.num_advice_columns,
                sha256.is_input_range_check, sha256.range().gate.max_rows as u64);
     BACKEND.with(|slot| {
         let mut slot = slot.borrow_mut();
-        if slot.as_ref().map(|b| b.key != key).unwrap_or(true) { *slot = Some(Backend::new(sha256, key.clone())?); }
+        if slot.as_ref().map(|b| b.key != key).unwrap_or(true) {
+            match Backend::new(sha256, key.clone()) { Ok(b) => *slot = Some(b), Err(_) => return Ok(None) }   // no device, no library: CPU
+        }
         let be = slot.as_mut().unwrap();
-        // The gadget lays the region out from (column 0, row 0): the reference's circuits open the region with
-        // their first digest (lib.rs:454-459, benches/digest.rs:92-93).  A circuit that assigns other cells
-        // first must pass its start row to hsw_pack_plan_query / hsw_witness_blocks_ex instead.
-        if sha256.cur_hash_idx == 0 {
-            if ctx.advice_alloc[0] != (0, 0) { return Err(Error::Synthesis); }
-            check(unsafe { sys::hsw_gadget_reset(be.gadget) })?;                 // = config.sha256.clone(), lib.rs:440
-        }
-        let h = sha256.cur_hash_idx;
-        let mut r = unsafe { std::mem::zeroed::<sys::hsw_hash_result>() };
-        check(unsafe { sys::hsw_gadget_digest(be.gadget, input.as_ptr(), input.len(), precomputed_input_len.unwrap_or(0), &mut r) })?;
-        // Debug builds re-check the region on the device before any cell is handed to halo2: every gate row, copy,
-        // range bound, lookup entry and chip tie at the place the constraint structure expects it (0.3 ms for the
-        // bench circuit).
-        #[cfg(debug_assertions)]
-        {
-            let mut rep = unsafe { std::mem::zeroed::<sys::hsw_verify_report>() };
-            check(unsafe { sys::hsw_gadget_verify(be.gadget, &mut rep) })?;
-            if rep.violations != 0 { return Err(Error::Synthesis); }
-        }
-        let mut rc = unsafe { std::mem::zeroed::<sys::hsw_result_cells>() };
-        check(unsafe { sys::hsw_gadget_result_cells(be.gadget, h, &mut rc) })?;
-        let mut view = unsafe { std::mem::zeroed::<sys::hsw_gadget_view>() };
-        check(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
-
-        // ---- this digest's gate cells: stream cells [prologue_cell, end_cell), column segment by column segment
+        let here = (ctx.advice_alloc[0], ctx.cells_to_lookup.len());
+        // ---- phase 1: the C side only.  Any refusal => Ok(None), ctx untouched.
+        let fetched = match fetch(be, sha256, here, ctx.zero_cell.is_some(), input, precomputed_input_len) {
+            Some(f) => f,
+            None => { be.expect = None; return Ok(None); }
+        };
+        // ---- phase 2: hand the cells to halo2.  Errors here are halo2's own and propagate.
+        let Fetched { r, rc, view, segs, end } = fetched;
+        let (ocol, c) = (view.origin_column, be.chip_columns as u64);
         let gate_cols: Vec<Column<Advice>> = sha256.range().gate.basic_gates[0].iter().map(|g| g.value).collect();
         let mut want: Vec<(u64, usize)> = vec![(rc.input_len_cell, usize::MAX)];            // (stream cell, slot in `got`)
         want.extend((0..rc.n_input_bytes).map(|i| (rc.input_bytes_cell0 + i, usize::MAX)));
@@ -174,17 +185,11 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
         for (k, w) in want.iter_mut().enumerate() { w.1 = k; }
         want.sort_unstable();
         let mut next_want = 0usize;
-        let (mut cell, end) = (r.prologue_cell, r.end_cell);
-        while cell < end {
-            let (mut col, mut row) = (0u64, 0u64);
-            check(unsafe { sys::hsw_gadget_cell_position(be.gadget, cell, &mut col, &mut row) })?;
-            // cells of this column that belong to the digest: up to the column's last used row or the digest's end
-            let (mut ecol, mut erow) = (0u64, 0u64);
-            check(unsafe { sys::hsw_gadget_cell_position(be.gadget, end - 1, &mut ecol, &mut erow) })?;
-            let n = if ecol == col { (erow - row + 1) as usize } else { column_used_rows(be, col)? - row as usize };
-            assert!(n <= be.stage_cells);
+        let mut cell = r.prologue_cell;
+        for &(col, row, n) in &segs {
+            // image column = FlexGate column - origin column (hsw_gadget_set_origin)
             check(unsafe { sys::hsw_download(be.engine, be.stage as *mut c_void,
-                                             (view.d_gate as *const u8).add(((col * be.max_rows + row) * 32) as usize) as *const c_void, n * 32) })?;
+                                             (view.d_gate as *const u8).add((((col - ocol) * be.max_rows + row) * 32) as usize) as *const c_void, n * 32) })?;
             for i in 0..n {
                 let v: F = fe(unsafe { &*be.stage.add(i) });
                 let a = ctx.region.assign_advice(|| "hsw", gate_cols[col as usize], row as usize + i, || Value::known(v))?;
@@ -193,7 +198,6 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
             cell += n as u64;
         }
         // ---- the spread-chip columns of this digest's blocks (spread.rs:196-233): rows [cursor0 / c, (cursor0 + limbs) / c)
-        let c = be.chip_columns as u64;
         let limbs = r.n_blocks as u64 * 2060 * (16 / sha256.spread_config.num_bits_lookup as u64);   // 2,060 spread() calls per block x limbs
         let (row0, row1) = (r.spread_cursor0 / c, (r.spread_cursor0 + limbs + c - 1) / c);
         for k in 0..be.chip_columns {
@@ -208,21 +212,21 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
             }
         }
         // ---- the lookup-advice column: RangeConfig::finalize (lib.rs:469) copies ctx.cells_to_lookup into it, in
-        // queue order, after the circuit's last gadget.  Queue this digest's entries with their VALUES (the cell
-        // handle only matters to `copy`, a no-op in this pass): finalize then fills the column exactly as in the
-        // CPU path, also when the circuit queues lookups of its own after the gadget.
+        // queue order, after the circuit's last gadget.  Queue this digest's entries with their VALUES behind the
+        // ones the circuit queued before (the gadget's own lookup stream starts at that index: set_origin): finalize
+        // then fills the column exactly as in the CPU path, also when the circuit queues more lookups afterwards.
         let n = (r.epilogue_lookup + 64 - r.prologue_lookup) as usize;        // prologue | blocks | 64 epilogue entries (2 per digest byte)
         check(unsafe { sys::hsw_download(be.engine, be.stage as *mut c_void,
                                          (view.d_lookup as *const u8).add((r.prologue_lookup * 32) as usize) as *const c_void, n * 32) })?;
+        // every entry is a copy of a gate cell of this digest; in this pass `copy` is a no-op and only the value
+        // matters, so the entries carry the handle of the digest's first cell
         let any_cell: Cell = got[0].as_ref().unwrap().cell();
         for i in 0..n {
             let v: F = fe(unsafe { &*be.stage.add(i) });
             ctx.cells_to_lookup.push(assigned(any_cell, v, 0));
         }
         // ---- the Context's own bookkeeping, as the CPU path leaves it: next free (column, row), the cached zero cell
-        let (mut ncol, mut nrow) = (0u64, 0u64);
-        check(unsafe { sys::hsw_gadget_cell_position(be.gadget, r.end_cell - 1, &mut ncol, &mut nrow) })?;
-        ctx.advice_alloc[0] = (ncol as usize, nrow as usize + 1);
+        ctx.advice_alloc[0] = (end.0 as usize, end.1 as usize + 1);
         ctx.total_advice += (r.end_cell - r.prologue_cell) as usize;
         if ctx.zero_cell.is_none() {                       // load_zero caches one cell per Context (A4-iii)
             ctx.zero_cell = Some(assigned(any_cell, F::zero(), 0));
@@ -230,6 +234,7 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
         sha256.cur_hash_idx += 1;                          // lib.rs:347
         sha256.spread_config.num_limb_sum += limbs as usize;                 // spread.rs:228
         sha256.spread_config.row_offset = ((r.spread_cursor0 + limbs) / c) as usize;   // spread.rs:229-231
+        be.expect = Some((ctx.advice_alloc[0], ctx.cells_to_lookup.len()));
 
         let pick = |slot: usize| -> AssignedValue<F> {
             let a = got[slot].as_ref().expect("result cell inside the digest's stream");
@@ -237,12 +242,66 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
             a.value().map(|x| v = *x);
             assigned(a.cell(), v, 0)
         };
-        Ok(AssignedHashResult {
+        Ok(Some(AssignedHashResult {
             input_len: pick(0),                                                           // lib.rs:124-125
             input_bytes: (0..rc.n_input_bytes as usize).map(|i| pick(1 + i)).collect(),    // lib.rs:170-173
             output_bytes: (0..32).map(|i| pick(1 + rc.n_input_bytes as usize + i)).collect(),   // lib.rs:317-324
-        })
+        }))
     })
+}
+
+/// Phase 1 of `digest_gpu`: position the gadget where the Context stands, run the digest on the GPU, fetch the
+/// positions.  `None` on ANY refusal of the C side -- the gadget is then out of step with the circuit and stays
+/// unused until the next synthesis pass starts (cur_hash_idx == 0).
+fn fetch<F: PrimeField>(be: &mut Backend, sha256: &Sha256DynamicConfig<F>, here: ((usize, usize), usize), zero_loaded: bool,
+                        input: &[u8], precomputed_input_len: Option<usize>) -> Option<Fetched> {
+    let ok = |rc: i32| if rc == sys::HSW_OK { Some(()) } else { None };
+    if sha256.cur_hash_idx == 0 {
+        // a new synthesis pass (= config.sha256.clone(), lib.rs:440): all cursors back, the region starts where the
+        // Context stands now.  HSW_ERR_TOO_LARGE (more than 17 columns from this row) and friends => CPU path.
+        ok(unsafe { sys::hsw_gadget_reset(be.gadget) })?;
+        ok(unsafe { sys::hsw_gadget_set_origin(be.gadget, (here.0).0 as u64, (here.0).1 as u64, zero_loaded as i32, here.1 as u64) })?;
+    } else if be.expect != Some(here) {
+        // the circuit used the gate / range chips between two digests: the gadget's layout (fixed when the pass
+        // started) no longer describes the region.  INTEGRATION.md section 3 -- the CPU path takes over.
+        return None;
+    }
+    let mut view = unsafe { std::mem::zeroed::<sys::hsw_gadget_view>() };
+    ok(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
+    if (view.origin_column + view.columns) as usize > sha256.range().gate.basic_gates[0].len() { return None; }   // NUM_ADVICE too small: let the CPU path say so
+    let h = sha256.cur_hash_idx;
+    let mut r = unsafe { std::mem::zeroed::<sys::hsw_hash_result>() };
+    ok(unsafe { sys::hsw_gadget_digest(be.gadget, input.as_ptr(), input.len(), precomputed_input_len.unwrap_or(0), &mut r) })?;
+    // Debug builds re-check the region on the device before any cell is handed to halo2: every gate row, copy,
+    // range bound, lookup entry and chip tie at the place the constraint structure expects it (0.3 ms for the
+    // bench circuit -- not free: release builds skip it).
+    #[cfg(debug_assertions)]
+    {
+        let mut rep = unsafe { std::mem::zeroed::<sys::hsw_verify_report>() };
+        ok(unsafe { sys::hsw_gadget_verify(be.gadget, &mut rep) })?;
+        if rep.violations != 0 { return None; }
+    }
+    let mut rc = unsafe { std::mem::zeroed::<sys::hsw_result_cells>() };
+    ok(unsafe { sys::hsw_gadget_result_cells(be.gadget, h, &mut rc) })?;
+    ok(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
+    // this digest's gate cells: stream cells [prologue_cell, end_cell), column segment by column segment
+    let pos = |cell: u64| -> Option<(u64, u64)> {
+        let (mut c, mut r_) = (0u64, 0u64);
+        ok(unsafe { sys::hsw_gadget_cell_position(be.gadget, cell, &mut c, &mut r_) })?;
+        Some((c, r_))
+    };
+    let end = pos(r.end_cell - 1)?;
+    let mut segs = Vec::new();
+    let mut cell = r.prologue_cell;
+    while cell < r.end_cell {
+        let (col, row) = pos(cell)?;
+        // cells of this column that belong to the digest: up to the column's last used row or the digest's end
+        let n = if end.0 == col { (end.1 - row + 1) as usize } else { column_used_rows(be, col)? - row as usize };
+        if n == 0 || n > be.stage_cells { return None; }
+        segs.push((col, row, n));
+        cell += n as u64;
+    }
+    Some(Fetched { r, rc, view, segs, end })
 }
 
 /// halo2-base v0.2.x `AssignedValue` (halo2-pse feature): { cell, value, row_offset, context_id }.
@@ -250,21 +309,22 @@ fn assigned<F: PrimeField>(cell: Cell, v: F, row_offset: usize) -> AssignedValue
     AssignedValue { cell, value: Value::known(v), row_offset, context_id: 0 }
 }
 
-/// Rows of column `col` that hold cells (the last rows of a column stay unassigned when the next call did not
-/// fit: A3-iii): the row of the last stream cell placed in it, plus one.
-fn column_used_rows(be: &Backend, col: u64) -> Result<usize, Error> {
-    // binary search for the last stream cell whose position is in `col`
+/// Rows of FlexGate column `col` that hold cells (the last rows of a column stay unassigned when the next call did
+/// not fit: A3-iii): the row of the last stream cell placed in it, plus one.
+fn column_used_rows(be: &Backend, col: u64) -> Option<usize> {
+    let ok = |rc: i32| if rc == sys::HSW_OK { Some(()) } else { None };
+    // binary search for the last stream cell whose position is in `col` (positions grow with the cell index)
     let mut view = unsafe { std::mem::zeroed::<sys::hsw_gadget_view>() };
-    check(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
+    ok(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
     let (mut lo, mut hi) = (0u64, view.gate_capacity);       // invariant: position(lo).col <= col
     while hi - lo > 1 {
         let mid = (lo + hi) / 2;
         let (mut c, mut r) = (0u64, 0u64);
-        check(unsafe { sys::hsw_gadget_cell_position(be.gadget, mid, &mut c, &mut r) })?;
+        ok(unsafe { sys::hsw_gadget_cell_position(be.gadget, mid, &mut c, &mut r) })?;
         if c <= col { lo = mid } else { hi = mid }
     }
     let (mut c, mut r) = (0u64, 0u64);
-    check(unsafe { sys::hsw_gadget_cell_position(be.gadget, lo, &mut c, &mut r) })?;
-    debug_assert_eq!(c, col);
-    Ok(r as usize + 1)
+    ok(unsafe { sys::hsw_gadget_cell_position(be.gadget, lo, &mut c, &mut r) })?;
+    if c != col { return None; }
+    Some(r as usize + 1)
 }

@@ -19,8 +19,13 @@ impl<F: PrimeField> Sha256DynamicConfig<F> {
         // create_proof's witness pass: every advice cell of this digest comes from the GPU (hsw.rs).
         // Key generation and MockProver -- the passes that record / check selectors, fixed cells and copy
         // constraints -- run the reference's own code.
-        if crate::hsw::witness_only_pass(ctx, self)? {
-            return crate::hsw::digest_gpu(self, ctx, input, precomputed_input_len);
+        // The region starts wherever `ctx` stands (hsw_gadget_set_origin); whatever the GPU side cannot do
+        // (Ok(None): no device, more than 17 columns, a Context that moved between two digests) falls through
+        // to the reference's own code on an untouched Context -- the GPU path never adds a failure mode.
+        if crate::hsw::witness_only_pass(ctx, self) {
+            if let Some(r) = crate::hsw::digest_gpu(self, ctx, input, precomputed_input_len)? {
+                return Ok(r);
+            }
         }
         self.digest_cpu(ctx, input, precomputed_input_len)
     }

@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(hsw):
     for name in declared:
         assert hasattr(lib, name), "libhsw.so does not export %s" % name
     assert set(declared) == set(hsw._native.SYMBOLS), "binding list out of sync with hsw.h"
-    assert lib.hsw_abi_version() == 2
+    assert lib.hsw_abi_version() == 3
 
 
 def test_every_bound_function_has_a_signature(hsw):
