@@ -478,7 +478,14 @@ int hsw_witness_frames(hsw_engine *e, const hsw_frame_desc *descs, size_t n, con
     return HSW_OK;
 } HSW_NO_UNWIND
 
-int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
+}  // extern "C"
+
+// dev_next_states: the DEVICE address of a->host_next_states when the caller already holds it (the gadget: its
+// own pinned staging, mapped once at creation), else NULL = ask the runtime.  The public entry point always asks:
+// round 2 cached one (host, device) pair per engine and translated every later pointer within 64 KiB above it by
+// offset -- a pointer from another (or from no) pinned allocation in that window skipped the check and the kernel
+// stored the next states through a stale or unmapped address.
+int hsw_witness_digests_impl(hsw_engine *e, const hsw_digests_args *a, uint32_t *dev_next_states) {
     if (!e || !a) return HSW_ERR_INVALID_ARG;
     const hsw_witness_args &b = a->blocks;
     if (a->n_digests == 0 || b.n_blocks == 0) return HSW_OK;
@@ -499,7 +506,7 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
         return set_err(e, HSW_ERR_INVALID_ARG, "blocks.n_blocks / frame_every do not match the digests");
     DeviceScope ds(e->device);
     if (!ds.ok) return set_err(e, HSW_ERR_NO_DEVICE, "hipSetDevice failed");
-    if (!hsw_small_eligible(e, b.n_blocks) || a->descs[0].n_blocks > 32) {      // (the frame waves stage <= 33 states in LDS)
+    if (!hsw_small_eligible(e, b.n_blocks) || a->descs[0].n_blocks > hsw::SMALL_FRAME_MAX_BLOCKS) {   // (the frame waves stage the candidate states in LDS)
         // two launches: the expansion, then the frames from the next states it left in HBM
         rc = hsw_witness_blocks_ex(e, &b);
         if (rc == HSW_OK)
@@ -534,22 +541,19 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
     fr.gate0 = a->d_gate0;
     fr.lookup0 = a->d_lookup0;
     fr.n_frames = (uint32_t)a->n_digests;
+    fr.max_frame_blocks = (uint32_t)max_blocks;
     fr.byte_waves = (uint32_t)(max_blocks > 32 ? 32 : max_blocks);                  // one wave per 64 input bytes
     // state waves: one frame cell per work item (hsw_frame_body.hpp), about two per thread -- each wave repeats the
     // last block's 64-round recurrence first, so more waves cost SIMDs, not time
     const size_t state_items = 192 + (size_t)hsw::frame::E_STATE * (max_blocks + 1) + 32 * 11;
     fr.state_waves = (uint32_t)((state_items + 127) / 128 < 16 ? (state_items + 127) / 128 : 16);
     fr.brk = brk;
-    uint32_t *host_next = nullptr;
-    if (a->host_next_states) {
-        // (a gadget hands in the same staging buffer at a moving offset: translate once per 64 KiB window)
-        const uintptr_t hp = (uintptr_t)a->host_next_states, lp = (uintptr_t)e->pin_host;
-        if (e->pin_host && hp >= lp && hp - lp < (1u << 16)) {
-            host_next = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(e->pin_dev) + (hp - lp));
-        } else {
-            hipError_t he = hipHostGetDevicePointer((void **)&host_next, a->host_next_states, 0);
-            if (he != hipSuccess) return set_err(e, HSW_ERR_INVALID_ARG, "host_next_states is not pinned, device-mapped host memory (hsw_host_alloc)", he);
-            e->pin_host = a->host_next_states; e->pin_dev = host_next;
+    uint32_t *host_next = dev_next_states;
+    if (a->host_next_states && !host_next) {
+        hipError_t he = hipHostGetDevicePointer((void **)&host_next, a->host_next_states, 0);
+        if (he != hipSuccess || !host_next) {
+            (void)hipGetLastError();
+            return set_err(e, HSW_ERR_INVALID_ARG, "host_next_states is not pinned, device-mapped host memory (hsw_host_alloc)", he);
         }
     }
     rc = hsw_witness_blocks_impl(e, &b, &fr, host_next);
@@ -560,6 +564,8 @@ int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
         slot->inflight = true;
     }
     return HSW_OK;
-} HSW_NO_UNWIND
+}
 
-}  // extern "C"
+extern "C" int hsw_witness_digests(hsw_engine *e, const hsw_digests_args *a) try {
+    return hsw_witness_digests_impl(e, a, nullptr);
+} HSW_NO_UNWIND

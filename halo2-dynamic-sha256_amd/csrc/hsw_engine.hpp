@@ -59,8 +59,6 @@ struct hsw_engine {
     int verify_slices = 0;               // workgroups per block in hsw_verify_kernel; 0 = default
     hsw::VerifyReport *d_report = nullptr;
     hsw_launch_info last_launch{};       // hsw_last_launch
-    const void *pin_host = nullptr;      // last pinned host pointer translated for hsw_witness_digests ...
-    void *pin_dev = nullptr;             // ... and its device address
 };
 
 inline int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSuccess) {
@@ -79,6 +77,7 @@ namespace hsw { struct SmallFrames; }
 bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks);
 int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
                             uint32_t *host_next_states);
+int hsw_witness_digests_impl(hsw_engine *e, const hsw_digests_args *args, uint32_t *dev_next_states);
 
 // Makes the engine's device current for the scope of one call (a no-op when it already is: the usual case,
 // and these scopes nest three deep on the latency-critical path of a small digest).

@@ -86,6 +86,9 @@ struct FrameBreaks {      // entries past n: cell = UINT64_MAX, gap = 0 (the dev
 
 // Whole-digest launches of the small-batch kernel (hsw_small.hpp): the frames are written by waves of the
 // same grid as the expansion.  Block indices in the descriptors are relative to blocks0 / pre0.
+// A frame wave stages its digest's candidate states (n_blocks + 1 of them) in LDS and prefetches the chain inputs
+// with four loads per lane: digests of up to this many blocks.  Checked where the kernel is launched (launch_small_L).
+constexpr uint32_t SMALL_FRAME_MAX_BLOCKS = 32;
 struct SmallFrames {
     const FrameDesc *descs;       // n_frames digests; may live in pinned, device-mapped host memory
     const uint64_t *inv_tbl;      // k^-1 table in the output representation (launch_frames)
@@ -95,6 +98,7 @@ struct SmallFrames {
     uint32_t n_frames;
     uint32_t state_waves;         // waves per digest on the cells that look at state words (they run the last block's chain)
     uint32_t byte_waves;          // waves per digest on the input-byte cells
+    uint32_t max_frame_blocks;    // largest n_blocks of any descriptor (host-computed; <= SMALL_FRAME_MAX_BLOCKS)
     FrameBreaks brk;              // column breaks in absolute gate-stream cells
     FrameDesc d0;                 // descs[0] by value: a single digest needs no read of host memory to get going
 };

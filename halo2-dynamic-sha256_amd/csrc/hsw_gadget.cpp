@@ -19,6 +19,7 @@
 bool hsw_small_eligible(const hsw_engine *e, size_t n_blocks);
 int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const hsw::SmallFrames *frames,
                             uint32_t *host_next_states);
+int hsw_witness_digests_impl(hsw_engine *e, const hsw_digests_args *args, uint32_t *dev_next_states);
 
 namespace hsw {
 
@@ -598,7 +599,8 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                     }
                     da.frame_pack = ctx.max_rows ? &abs_plan : nullptr;
                     da.host_next_states = h_next + 8 * ob;
-                    rc = hsw_witness_digests(ctx.engine, &da);
+                    // (the device alias of the context's own pinned staging: no runtime lookup per call)
+                    rc = hsw_witness_digests_impl(ctx.engine, &da, ctx.dp_next + 8 * (b0 + ob));
                     next_in_pinned = rc == HSW_OK;
                 } else {
                     rc = hsw_witness_blocks_ex(ctx.engine, &a);

@@ -432,7 +432,10 @@ __global__ __launch_bounds__(64 * HSW_SMALL_MAX_HELPERS) void hsw_small_kernel(E
             // last block's output comes from the recurrence itself, computed here
             const u32 *ps0 = fr.pre0 + 8 * d.first_block, *ps_last = ps0 + 8 * (d.n_blocks - 1);
             // (the pre-states may sit in pinned host memory: fetch them now, they arrive while the chain runs)
-            __shared__ u32 s_states[8 * 34];             // a small-batch launch has at most 32 blocks
+            // (digests of at most SMALL_FRAME_MAX_BLOCKS blocks each -- enforced by launch_small_L; the launch itself
+            // may hold up to 128 blocks, or any number with split = 2)
+            __shared__ u32 s_states[8 * (SMALL_FRAME_MAX_BLOCKS + 2)];
+            static_assert(8 * SMALL_FRAME_MAX_BLOCKS <= 4 * 64, "four prefetch loads per lane cover the chain inputs");
             const u32 nw = 8u * d.n_blocks;
             u32 pre_w[4];
 #pragma unroll
@@ -529,6 +532,9 @@ hipError_t launch_small_L(const ExpandParams &p, const SmallFrames *fr, hipStrea
     if (fr) f = *fr;
     const bool rc = (p.flags & HSW_K_INTERNALS) != 0u;
     if (f.n_frames && (!rc || (p.flags & HSW_K_COMPACT))) return hipErrorInvalidValue;
+    // the frame waves' LDS staging and prefetch are sized for digests of <= SMALL_FRAME_MAX_BLOCKS blocks
+    if (f.n_frames && (f.max_frame_blocks == 0 || f.max_frame_blocks > SMALL_FRAME_MAX_BLOCKS ||
+                       f.d0.n_blocks > f.max_frame_blocks)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(p.n_blocks * SMALL_ROLES + (size_t)f.n_frames * (f.state_waves + f.byte_waves))), block(64 * helpers);
     if (rc) {
         if (p.flags & HSW_K_MONTGOMERY) hipLaunchKernelGGL((hsw_small_kernel<L, 1, true>), grid, block, 0, stream, p, f);

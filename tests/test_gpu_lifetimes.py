@@ -1,0 +1,94 @@
+"""Lifetimes on the real runtime (the CPU sanitizer build with a stand-in runtime covers the host bookkeeping:
+tests/test_host_sanitizers.py): an engine destroyed with launches still queued, and hsw_witness_digests' public
+entry -- bit-exact against the oracle, next states delivered into pinned memory by the kernel itself, and an
+unpinned host_next_states refused on EVERY call (a cached translation once let a pointer near an
+earlier pinned one through)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_destroyed_with_work_in_flight(hsw, oracle):
+    """hsw_engine_destroy drains the engine's streams before it frees what queued launches use."""
+    import torch
+    rng = np.random.default_rng(7)
+    n = 1024
+    blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    pre = np.tile(oracle.INIT_STATE, (n, 1))
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks[:2], pre[:2])
+    for _ in range(3):
+        eng = hsw.WitnessEngine(0, 8, 2)
+        out = eng.witness_blocks(tb, tp)          # asynchronous: ~0.5 ms of kernel
+        eng.witness_blocks(tb, tp, out=out)
+        eng.close()                               # no synchronize() first
+        torch.cuda.synchronize()
+        assert np.array_equal(out["gate"][: 2 * 66308].cpu().numpy().view(np.uint64), ref["gate"])
+        assert np.array_equal(out["next_states"][:2].cpu().numpy().view(np.uint32), ref["next_states"])
+
+
+def test_witness_digests_public_entry_and_pinned_pointer_check(hsw, oracle):
+    import torch
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+    msg, mx = b"abc", 128
+    ref = oracle.digest_cells([msg], [mx], None, True)
+    blocks_b, init, info = N.digest_prepare(msg, mx)
+    nb = mx // 64
+    blocks = np.frombuffer(bytes(blocks_b), dtype=np.uint8).reshape(nb, 64).copy()
+    pre = np.zeros((nb, 8), dtype=np.uint32)
+    st = np.array(init, dtype=np.uint32)
+    for b in range(nb):
+        pre[b] = st
+        st = np.array(oracle.plain_compress(st, blocks[b]), dtype=np.uint32)
+    fs = N.FrameShape()
+    assert eng.lib.hsw_frame_query(C.byref(eng.shape), mx, 1, C.byref(fs)) == N.HSW_OK
+    G, LK = eng.G, eng.lookup_cells
+    t = torch
+    tb, tp = t.from_numpy(blocks).cuda(), t.from_numpy(pre.view(np.int32)).cuda()
+    gate = t.zeros((int(fs.digest_cells) + 1, 4), dtype=t.int64, device="cuda")
+    lookup = t.zeros((int(fs.digest_lookups), 4), dtype=t.int64, device="cuda")
+    rows = eng.chip_rows(0, nb)
+    dense, spread = (t.zeros((2, rows, 4), dtype=t.int64, device="cuda") for _ in range(2))
+    nxt = t.zeros((nb, 8), dtype=t.int32, device="cuda")
+    d = N.FrameDesc()
+    d.input_len, d.first_block, d.n_blocks, d.num_round, d.precomputed_round, d.is_input_range_check = len(msg), 0, nb, 1, 0, 1
+    d.prologue_cell, d.zero_cell = 0, int(fs.prologue_cells)
+    block_cell = int(fs.prologue_cells) + 1
+    d.epilogue_cell = block_cell + nb * G
+    d.prologue_lookup, d.epilogue_lookup = 0, int(fs.prologue_lookups) + nb * LK
+    a = N.DigestsArgs()
+    a.blocks.d_blocks, a.blocks.d_pre_states, a.blocks.n_blocks = tb.data_ptr(), tp.data_ptr(), nb
+    a.blocks.d_gate = gate.data_ptr() + 32 * block_cell
+    a.blocks.d_chip_dense, a.blocks.d_chip_spread, a.blocks.chip_col_stride = dense.data_ptr(), spread.data_ptr(), rows
+    a.blocks.d_next_states = nxt.data_ptr()
+    a.blocks.d_lookup = lookup.data_ptr() + 32 * int(fs.prologue_lookups)
+    a.descs, a.n_digests = C.addressof(d), 1
+    a.d_blocks0, a.d_pre_states0, a.d_next_states0 = tb.data_ptr(), tp.data_ptr(), nxt.data_ptr()
+    a.d_gate0, a.d_lookup0 = gate.data_ptr(), lookup.data_ptr()
+    pinned = eng.host_empty((64,))
+    pinned[:] = 0
+    a.host_next_states = pinned.ctypes.data + 64                      # inside a pinned allocation, at an offset
+    assert eng.lib.hsw_witness_digests(eng.h, C.byref(a)) == N.HSW_OK
+    eng.synchronize()
+    assert eng.last_launch()["split"] == 2                             # ONE launch: frames rode on the small-batch kernel
+    assert np.array_equal(gate.cpu().numpy().view(np.uint64), ref["gate"])
+    assert np.array_equal(lookup.cpu().numpy().view(np.uint64), ref["lookup"])
+    assert np.array_equal(dense.cpu().numpy().view(np.uint64), ref["dense"][:, :rows])
+    host_next = pinned.view(np.uint32)[16: 16 + 8 * nb].reshape(nb, 8)
+    assert np.array_equal(host_next, nxt.cpu().numpy().view(np.uint32))
+    sel = host_next[int(info["target_round"]) - 1]
+    assert b"".join(int(w).to_bytes(4, "big") for w in sel) == hashlib.sha256(msg).digest()
+    # ordinary heap memory right after a pinned pointer has been used: refused, nothing launched
+    heap = np.zeros(64, dtype=np.uint32)
+    a.host_next_states = heap.ctypes.data
+    assert eng.lib.hsw_witness_digests(eng.h, C.byref(a)) == N.HSW_ERR_INVALID_ARG
+    assert b"pinned" in eng.lib.hsw_last_error(eng.h)
+    a.host_next_states = None
+    assert eng.lib.hsw_witness_digests(eng.h, C.byref(a)) == N.HSW_OK
+    eng.synchronize()
+    eng.close()
