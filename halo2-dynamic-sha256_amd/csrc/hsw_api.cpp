@@ -66,6 +66,29 @@ void fill_shape(hsw_shape *s) {
 //    of them (lane = unit) or they can be dealt to 2..16 waves.  Small batches
 //    (e.g. the 16-block message of BASELINE configs[1]) need the split to
 //    occupy 256 CUs.
+// The byte tables of the emit-time Montgomery kernels (hsw_expand.hpp Em::M32): i, spread(i) and i << 8 for
+// i < 256 in Montgomery form, 3 x 256 cells.  x * R mod p is additive in x, so any 16-bit value is two entries and
+// one field addition.  Built once per engine on the host (hsw_fr.hpp), 24 KiB, read through L1 / L2.
+int ensure_mont_tab(hsw_engine *e) {
+    if (e->d_mont_tab) return HSW_OK;
+    std::vector<uint64_t> h(3 * 256 * 4);
+    for (uint64_t i = 0; i < 256; i++) {
+        uint64_t sp = 0;
+        for (int b = 0; b < 8; b++) sp |= ((i >> b) & 1ull) << (2 * b);
+        const uint64_t vals[3] = {i, sp, i << 8};
+        for (int t = 0; t < 3; t++) {
+            const hsw::fr::Fe m = hsw::fr::to_mont(hsw::fr::Fe{{vals[t], 0, 0, 0}});
+            std::memcpy(&h[(size_t)(t * 256 + i) * 4], m.l, 32);
+        }
+    }
+    void *d = nullptr;
+    hipError_t he = hipMalloc(&d, h.size() * 8);
+    if (he == hipSuccess) he = hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { if (d) (void)hipFree(d); return set_err(e, he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP, "Montgomery byte tables", he); }
+    e->d_mont_tab = d;
+    return HSW_OK;
+}
+
 int choose_tile(const hsw_engine *e, uint32_t flags) {
     if (e->limbs != 2) return 32;                 // other tile shapes are built for the 8-bit table only
     if (e->tile > 0) return e->tile;
@@ -222,6 +245,7 @@ void hsw_engine_destroy(hsw_engine *e) {
             if (fs.done) (void)hipEventDestroy(fs.done);
         }
         if (e->d_structure) (void)hipFree(e->d_structure);
+        if (e->d_mont_tab) (void)hipFree(e->d_mont_tab);
         if (e->d_report) (void)hipFree(e->d_report);
         if (e->d_inv_tbl[0]) (void)hipFree(e->d_inv_tbl[0]);
         if (e->d_inv_tbl[1]) (void)hipFree(e->d_inv_tbl[1]);
@@ -278,6 +302,11 @@ int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value) try {
     if (std::strcmp(name, "helpers") == 0) {
         if (value < 0 || value > HSW_SMALL_MAX_HELPERS) return set_err(e, HSW_ERR_INVALID_ARG, "helpers must be 0 (auto) .. 4");
         e->helpers = (int)value;
+        return HSW_OK;
+    }
+    if (std::strcmp(name, "mont_emit") == 0) {
+        if (value < 0 || value > 2) return set_err(e, HSW_ERR_INVALID_ARG, "mont_emit must be 0, 1 or 2");
+        e->mont_emit = (int)value;
         return HSW_OK;
     }
     if (std::strcmp(name, "tile") == 0) {
@@ -442,6 +471,19 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             p.parts = 32;
             p.flags |= hsw::HSW_K_SPLIT;
         }
+        // Montgomery cells, streaming kernel, the reference's 8-bit table: converted at emit time, [64][16] tiles of
+        // finished 32-byte cells, one wave per block (hsw_expand.hpp Em::M32)
+        // (default mode only unless forced: with the internals-mode tile -- realignment columns, lookup staging -- it
+        //  drops to 4 waves per CU and loses to the write-out conversion, 2.35 vs 1.96 ms)
+        const bool m32 = !small && e->limbs == 2 && (flags & HSW_REPR_MONTGOMERY) && !(p.flags & hsw::HSW_K_SPLIT) &&
+                         (e->mont_emit == 2 || (e->mont_emit == 1 && e->mode != HSW_MODE_HALO2_INTERNALS));
+        if (m32) {
+            const int rc = ensure_mont_tab(e);
+            if (rc != HSW_OK) return rc;
+            p.flags |= hsw::HSW_K_M32;
+            p.parts = 1;
+            p.mont_tab = e->d_mont_tab;
+        }
         if (args->pack) {
             // breaks are given in call-relative stream indices; this launch starts at cell done*G
             for (uint32_t k = 0; k < args->pack->n_breaks; k++) {
@@ -489,9 +531,9 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             hsw_launch_info &li = e->last_launch;
             const bool wide_internals = e->mode == HSW_MODE_HALO2_INTERNALS && e->limbs > 2;   // [64][32] tiles only
             li.limbs = (uint32_t)e->limbs;
-            li.tile_cells = wide_internals ? 32u : tile == 6416 ? 64u : (uint32_t)tile;
-            li.tile_rows = wide_internals ? 64u : tile == 6416 ? 16u : 2048u / (uint32_t)tile;
-            li.repr = (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
+            li.tile_cells = m32 ? 16u : wide_internals ? 32u : tile == 6416 ? 64u : (uint32_t)tile;
+            li.tile_rows = m32 ? 64u : wide_internals ? 64u : tile == 6416 ? 16u : 2048u / (uint32_t)tile;
+            li.repr = m32 ? 3u : (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
             li.internals = e->mode == HSW_MODE_HALO2_INTERNALS ? 1u : 0u;
             li.parts = p.parts;
             li.split = (p.flags & hsw::HSW_K_SPLIT) ? 1u : 0u;

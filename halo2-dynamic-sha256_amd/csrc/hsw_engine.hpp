@@ -24,6 +24,8 @@ struct hsw_engine {
     int split = -1;            // -1 = small-batch kernel for <= 32 blocks, 0 = never, 1 = one phase per wave (32 waves per
                                // block) in hsw_expand_kernel, 2 = small-batch kernel always
     int tile = 0;              // tile width in cells: 0 = choose, 32, 64 or 128
+    int mont_emit = 1;         // Montgomery cells of the streaming kernel: converted at emit time (Em::M32) -- 0 = never,
+                               // 1 = in default mode (where it wins), 2 = also in internals mode; else at write-out
     size_t chunk_blocks = (size_t)1 << 20;   // blocks per launch (longer batches are consecutive launches)
     uint32_t mode = HSW_MODE_DEFAULT;
     bool timing = false;
@@ -59,6 +61,7 @@ struct hsw_engine {
     int verify_slices = 0;               // workgroups per block in hsw_verify_kernel; 0 = default
     hsw::VerifyReport *d_report = nullptr;
     hsw_launch_info last_launch{};       // hsw_last_launch
+    void *d_mont_tab = nullptr;          // Em::M32 kernels: Montgomery form of every byte, its spread, and the byte << 8 (24 KiB)
 };
 
 inline int set_err(hsw_engine *e, int status, const char *what, hipError_t he = hipSuccess) {

@@ -18,6 +18,8 @@ enum : uint32_t {
     HSW_K_SPLIT = 32u,       // 32 waves per block, each running one phase program (tiny batches: latency)
     HSW_K_CHAINED = 64u,     // small-batch kernel: the blocks are ONE message, pre_states holds its initial state only
     HSW_K_ROLE_MAJOR = 128u, // small-batch kernel: grid = role x block instead of block x role (hsw_small.hpp)
+    HSW_K_M32 = 256u,        // with HSW_K_MONTGOMERY, streaming kernel, 8-bit table: Montgomery form built at EMIT time, tiles of
+                             // finished 32-byte cells (hsw_expand.hpp Em::M32); else one conversion per cell at write-out
 };
 enum { HSW_K_MAX_BREAKS = 16 };
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)
@@ -51,6 +53,7 @@ struct ExpandParams {
     // next digest's prologue, written by hsw_frame_kernel); frame_every = 0: off
     uint64_t frame_every, frame_cells, frame_lookups;
     uint32_t *next_states_host;   // small-batch kernel only: a second copy of next_states, in pinned host memory (may be null)
+    const void *mont_tab;         // HSW_K_M32 only: 3 x 256 Montgomery-form cells -- i, spread(i), i << 8 for i < 256 (hsw_api.cpp)
 };
 
 // limbs = 16 / num_bits_lookup.  Returns hipErrorInvalidValue for a limb count

@@ -130,7 +130,7 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
     constexpr int B = 16 / L;
     constexpr u32 MASK = (1u << B) - 1u;
     if (sub_calls == 0 || (p.flags & HSW_K_SKIP_CHIP)) return;
-    __syncthreads();                                                   // d16 staged by all lanes
+    em_sync<EM>();                                                     // d16 staged by all lanes
     const u32 lane = lane_id();
     const u32 per_row = sub_calls * (u32)L, total = em.nrows * per_row;
     // one 64-bit division per wave (scalar), 32-bit ones per limb: limb n0 + x sits in column (c0 + x) % ncols
@@ -152,7 +152,7 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
         if constexpr (EM::COMPACT) {
             store8(cd, 0, limb);
             store8(cs, 0, spread16(limb));
-        } else if constexpr (EM::MONT) {
+        } else if constexpr (EM::MONT_OUT) {
             const Fe8 md = mont_from_u64<false>(limb, 0), ms = mont_from_u64<false>(spread16(limb), 0);
             store16(cd, 0, make_uint4(md.l[0], md.l[1], md.l[2], md.l[3]));
             store16(cd, 16, make_uint4(md.l[4], md.l[5], md.l[6], md.l[7]));
@@ -165,7 +165,7 @@ DEV void scatter_chip(const EM &em, const ExpandParams &p, u64 block_first_limb,
             store16(cs, 16, make_uint4(0u, 0u, 0u, 0u));
         }
     }
-    __syncthreads();
+    em_sync<EM>();
 }
 
 // Lookup-advice entries of a sub-unit phase (RC only): row r's are lk0 + r * lk_per_unit + [0, sub_lk).
@@ -173,7 +173,7 @@ template <class EM>
 DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block_base, u32 lk0, u32 lk_per_unit,
                         u32 sub_lk) {
     if (sub_lk == 0 || p.lookup == nullptr) return;
-    __syncthreads();
+    em_sync<EM>();
     const u32 lane = lane_id();
     const u32 total = em.nrows * sub_lk;
     const u32 hs = em.hsel, hn = em.hcnt;             // all waves of the workgroup, the emitter included
@@ -185,7 +185,7 @@ DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block
             reinterpret_cast<u64 *>(p.lookup)[at] = v;
         } else {
             uint4 *out = reinterpret_cast<uint4 *>(p.lookup) + at * 2u;
-            if constexpr (EM::MONT) {
+            if constexpr (EM::MONT_OUT) {
                 const Fe8 m = mont_from_u64<false>(v, 0);
                 out[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
                 out[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
@@ -195,14 +195,17 @@ DEV void scatter_lookup(const EM &em, const ExpandParams &p, size_t lookup_block
             }
         }
     }
-    __syncthreads();
+    em_sync<EM>();
 }
 
 template <int L, class EM, class C>
 DEV void sub_end(C, EM &em, const ExpandParams &p, u64 block_first_limb, size_t lookup_block_base, u32 call0,
                  u32 calls_per_unit, u32 sub_calls, u32 lk0, u32 lk_per_unit, u32 sub_lk) {
     HSW_STAMP(5);
-    if constexpr (C::pos != 0) flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+    if constexpr (C::pos != 0) {
+        if constexpr (EM::M32) flush_tile32<EM, false>(em, C::pos, C::fl);
+        else flush_tile<EM, false>(em, C::pos, C::fl, C::na, C::nb, C::nc, C::nd, C::cn);
+    }
     HSW_STAMP(6);
     scatter_chip<L>(em, p, block_first_limb, call0, calls_per_unit, sub_calls);
     HSW_STAMP(7);
@@ -219,12 +222,13 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
     EM em;
     em.lk16 = s_lk16;
     em.tile = s_tile;
-    em.row0 = s_tile + (lane < (u32)SMALL_ROWS ? lane : (u32)SMALL_ROWS) * EM::STRIDE;
+    em.row0 = s_tile + (lane < (u32)SMALL_ROWS ? lane : (u32)SMALL_ROWS) * EM::STRIDE_W;
     em.row = em.row0;
     em.skew = 0;
     em.carry_neg = 0;
     em.head = nullptr;
     em.d16 = s_d16;
+    em.tab = nullptr;
     em.hsel = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform (the flush loops stay scalar); blockDim.x / 64 waves share the role
     em.hcnt = blockDim.x >> 6;
 
@@ -273,37 +277,36 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
             sub_end<L>(cur, em, p, blk_limb0, lk_blk, call0 + SP::off(SP::R_CALLS, k), LY::CALLS_ROUND, SP::R_CALLS[k],
                        lk0 + SP::off(SP::R_LK, k), LY::LK_ROUND, SP::R_LK[k]);
         };
-        u32 sig1, chv, t1, sig0, mjv, t2, e_new, a_new;
-        u64 s;
+        W<EM> sig1, chv, t1, sig0, mjv, t2, e_new, a_new, s;
         if (type == 0) {
             begin(0);
             end(sigma_generic<SigmaUpper1, L>(CurStart{}, em, e, sig1), 0);                 // :130
         } else if (type == 1) {
             begin(1);
-            end(ch_part_a<L>(CurStart{}, em, ch_values(e, f, g)), 1);                       // :131 (:309-365)
+            const ChVals cv = ch_values(e, f, g);
+            end(ch_part_a<L>(CurStart{}, em, cv, ch_witnesses(em, cv)), 1);                 // :131 (:309-365)
         } else if (type == 2) {
             begin(2);
-            sig1 = sha_S1(e);
-            auto c2 = ch_part_b<L>(CurStart{}, em, ch_values(e, f, g), chv);                // :131 (:366-403)
-            auto c3 = g_add(c2, em, h, sig1, s);                                            // :138-142
+            const ChVals cv = ch_values(e, f, g);
+            auto c2 = ch_part_b<L>(CurStart{}, em, cv, ch_witnesses(em, cv), chv);          // :131 (:366-403)
+            auto c3 = g_add(c2, em, w32<EM>(h), w32<EM>(sha_S1(e)), s);                     // :138-142
             auto c4 = g_add(c3, em, s, chv, s);                                             // :143-147
-            auto c5 = g_add(c4, em, s, kr, s);                                              // :148-152
-            auto c6 = g_add(c5, em, s, wr, s);                                              // :153-157
+            auto c5 = g_add(c4, em, s, wround_constant<EM>(unit_lo + lane), s);             // :148-152
+            auto c6 = g_add(c5, em, s, w32<EM>(wr), s);                                     // :153-157
             end(mod_u32(c6, em, s, t1), 2);                                                 // :158
         } else if (type == 3) {
             begin(3);
             end(sigma_generic<SigmaUpper0, L>(CurStart{}, em, a, sig0), 3);                 // :164
         } else if (type == 4) {
             begin(4);
-            sig0 = sha_S0(a);
             auto c9 = maj_gadget<L>(CurStart{}, em, a, b, c, mjv);                          // :165
-            auto c10 = g_add(c9, em, sig0, mjv, s);                                         // :166-170
+            auto c10 = g_add(c9, em, w32<EM>(sha_S0(a)), mjv, s);                           // :166-170
             end(mod_u32(c10, em, s, t2), 4);                                                // :171
         } else {
             begin(5);
-            t1 = h + sha_S1(e) + sha_ch(e, f, g) + kr + wr;
-            t2 = sha_S0(a) + sha_maj(a, b, c);
-            auto c12 = g_add(CurStart{}, em, d, t1, s);                                     // :181
+            t1 = w32<EM>(h + sha_S1(e) + sha_ch(e, f, g) + kr + wr);
+            t2 = w32<EM>(sha_S0(a) + sha_maj(a, b, c));
+            auto c12 = g_add(CurStart{}, em, w32<EM>(d), t1, s);                            // :181
             auto c13 = mod_u32(c12, em, s, e_new);                                          // :182
             auto c14 = state_to_spread<L>(c13, em, e_new);                                  // :184
             auto c15 = g_add(c14, em, t1, t2, s);                                           // :192
@@ -326,17 +329,16 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
             sub_end<L>(cur, em, p, blk_limb0, lk_blk, call0 + SP::off(SP::S_CALLS, k), LY::CALLS_SCHED, SP::S_CALLS[k],
                        lk0 + SP::off(SP::S_LK, k), LY::LK_SCHED, SP::S_LK[k]);
         };
-        u32 term1, term3, new_w;
-        u64 sum;
+        W<EM> term1, term3, new_w, sum;
         if (type == 0) {
             end(sigma_generic<SigmaLower1, L>(CurStart{}, em, w2, term1), 0);               // :60
         } else if (type == 1) {
             end(sigma_generic<SigmaLower0, L>(CurStart{}, em, w15, term3), 1);              // :61
         } else {
-            term1 = sha_s1(w2); term3 = sha_s0(w15);
-            auto c3 = g_add(CurStart{}, em, term1, w7, sum);                                // :65-69
+            term1 = w32<EM>(sha_s1(w2)); term3 = w32<EM>(sha_s0(w15));
+            auto c3 = g_add(CurStart{}, em, term1, w32<EM>(w7), sum);                       // :65-69
             auto c4 = g_add(c3, em, sum, term3, sum);                                       // :70-74
-            auto c5 = g_add(c4, em, sum, w16, sum);                                         // :75-79
+            auto c5 = g_add(c4, em, sum, w32<EM>(w16), sum);                                // :75-79
             auto c6 = mod_u32(c5, em, sum, new_w);                                          // :80
             end(state_to_spread<L>(c6, em, new_w), 2);                                      // :90
         }
@@ -356,9 +358,8 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
         }
         HSW_STAMP(2);
         if (phase_begin(em, 0, 1, 8, LY::FEED, LY::OFF_FEED, 0, 0, LY::LK_OFF_FEED, LY::LK_FEED)) {
-            u64 s;
-            u32 lo;
-            auto c1 = g_add(CurStart{}, em, fx, fy, s);
+            W<EM> s, lo;
+            auto c1 = g_add(CurStart{}, em, w32<EM>(fx), w32<EM>(fy), s);
             auto c2 = mod_u32(c1, em, s, lo);
             phase_end<L>(c2, em, p, blk_limb0, lk_blk);
         }
@@ -368,13 +369,7 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
         const u32 word = __builtin_bswap32(bw[lane & 15u]);
         HSW_STAMP(1); HSW_STAMP(2);
         if (phase_begin(em, 0, 1, 16, LY::WORD, LY::OFF_WORDS, 0, 0)) {
-            const u32 b0 = word & 0xffu, b1 = (word >> 8) & 0xffu, b2 = (word >> 16) & 0xffu, b3 = word >> 24;
-            const u32 s0 = b0, s1 = s0 | (b1 << 8), s2 = s1 | (b2 << 16);
-            auto c1 = g_mul_add(CurStart{}, em, b0, 1u, 0u, s0);
-            auto c2 = g_mul_add(c1, em, b1, 1u << 8, s0, s1);
-            auto c3 = g_mul_add(c2, em, b2, 1u << 16, s1, s2);
-            auto c4 = g_mul_add(c3, em, b3, 1u << 24, s2, word);
-            phase_end<L>(c4, em, p, blk_limb0, lk_blk);
+            phase_end<L>(word_unit(CurStart{}, em, word), em, p, blk_limb0, lk_blk);
         }
         HSW_STAMP(3);
     } else if (role == SMALL_ROLE_MSG) {
@@ -382,7 +377,7 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
         const u32 word = __builtin_bswap32(bw[lane & 15u]);
         HSW_STAMP(1); HSW_STAMP(2);
         if (phase_begin(em, 0, 1, 16, LY::S2S, LY::OFF_MSG, LY::CALL_MSG, LY::CALLS_S2S)) {
-            auto c1 = state_to_spread<L>(CurStart{}, em, word);
+            auto c1 = state_to_spread<L>(CurStart{}, em, w32<EM>(word));
             phase_end<L>(c1, em, p, blk_limb0, lk_blk);
         }
         HSW_STAMP(3);
@@ -394,7 +389,7 @@ DEV void small_role(const ExpandParams &p, const u32 *bw, const u32 (&ps)[8], si
         for (int i = 1; i < 7; i++) word = wi == (u32)i ? ps[i] : word;
         HSW_STAMP(1); HSW_STAMP(2);
         if (phase_begin(em, 0, 1, 6, LY::S2S, LY::OFF_STATE, LY::CALL_STATE, LY::CALLS_S2S)) {
-            auto c1 = state_to_spread<L>(CurStart{}, em, word);
+            auto c1 = state_to_spread<L>(CurStart{}, em, w32<EM>(word));
             phase_end<L>(c1, em, p, blk_limb0, lk_blk);
         }
         HSW_STAMP(3);
@@ -405,7 +400,7 @@ template <int L, int REPR, bool RC>
 __global__ __launch_bounds__(64 * HSW_SMALL_MAX_HELPERS) void hsw_small_kernel(ExpandParams p, SmallFrames fr) {
     using SP = SmallPlan<L, RC>;
     using EM = Em<SMALL_TILE, SMALL_ROWS, REPR, RC, true>;
-    __shared__ u64 s_tile[(SMALL_ROWS + 1) * EM::STRIDE];                   // +1 scratch row for lanes >= 16
+    __shared__ __attribute__((aligned(16))) u64 s_tile[(SMALL_ROWS + 1) * EM::STRIDE_W];   // +1 scratch row for lanes >= 16
     __shared__ u16 s_d16[SMALL_ROWS * SP::MAX_CALLS];
     __shared__ u16 s_lk16[RC ? SMALL_ROWS * SP::MAX_LK : 1];
     HSW_STAMP(0);

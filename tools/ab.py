@@ -1,30 +1,37 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of libhsw builds in ONE process (tuning aid, not product).
-usage: tools_ab.py n_blocks reps libA.so[:parts] libB.so[:parts] ..."""
+usage: ab.py n_blocks reps lib.so[:parts[:tile[:flags[:opt=value,opt=value]]]] ...   (flags: HSW_REPR_* bits)"""
 import ctypes as C, sys, json
 import numpy as np, torch
+import os
 n = int(sys.argv[1]); reps = int(sys.argv[2])
+MODE = int(os.environ.get("HSW_AB_MODE", "0"))        # 1 = HSW_MODE_HALO2_INTERNALS (G = 69,348 cells per block)
 variants = []
 for spec in sys.argv[3:]:
-    path, parts, tile, vflags = (spec.split(":") + ["", "", ""])[:4]
+    path, parts, tile, vflags, opts = (spec.split(":") + ["", "", "", ""])[:5]
     L = C.CDLL(path)
     L.hsw_engine_create.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.hsw_witness_blocks.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_uint64] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_uint32]
     L.hsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.hsw_set_timing.argtypes = [C.c_void_p, C.c_int]
     h = C.c_void_p()
-    assert L.hsw_engine_create(0, None, 8, 2, C.byref(h)) == 0
+    L.hsw_engine_create_ex.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    assert L.hsw_engine_create_ex(0, None, 8, 2, MODE, C.byref(h)) == 0
     L.hsw_set_timing(h, 1)
     if parts:
         L.hsw_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         assert L.hsw_engine_set_option(h, b"parts", int(parts)) == 0
         if tile:
             assert L.hsw_engine_set_option(h, b"tile", int(tile)) == 0
+    for kv in filter(None, opts.split(",")):
+        L.hsw_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        k, v = kv.split("=")
+        assert L.hsw_engine_set_option(h, k.encode(), int(v)) == 0, kv
     variants.append((spec, L, h, int(vflags or 0)))
 rng = np.random.default_rng(0xC3)
 blocks = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
 pre = torch.from_numpy(np.tile(np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32).view(np.int32), (n, 1))).cuda()
-G = 66308
+G = 69348 if MODE else 66308
 gate = torch.empty((n * G, 4), dtype=torch.int64, device="cuda")  # sized for 32-byte cells; compact runs use a quarter
 dense = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
 spread = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
