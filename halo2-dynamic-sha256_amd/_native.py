@@ -32,6 +32,7 @@ HSW_MODE_HALO2_INTERNALS = 1
 HSW_MAX_BREAKS = 16
 HSW_CELL_BYTES = 32
 HSW_GADGET_WHOLE_DIGEST = 1
+HSW_GADGET_INDEPENDENT = 2
 NO_CELL = (1 << 64) - 1
 
 

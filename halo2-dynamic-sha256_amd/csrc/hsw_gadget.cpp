@@ -226,7 +226,7 @@ void Context::free_compact_staging() {
     wide_cap = 0;
 }
 
-int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest) const {
+int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest, bool independent) const {
     if (!engine || !out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
@@ -252,8 +252,14 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     if (whole_digest) {
         if (s.mode != HSW_MODE_HALO2_INTERNALS) { delete c; return HSW_ERR_INVALID_ARG; }
         c->whole = true;
-        uint64_t cells = 1, lookups = 0;                      // 1: the Context's zero cell
+        c->independent = independent;
+        // the Context's zero cell: one, or one per digest when every digest is a Context of its own
+        uint64_t cells = independent ? max_variable_byte_sizes.size() : 1, lookups = 0;
         for (size_t b : max_variable_byte_sizes) {
+            if (independent && ((b / 64) * (uint64_t)s.limb_calls_per_block) % s.num_advice_columns != 0) {
+                delete c;
+                return HSW_ERR_UNSUPPORTED;                   // a context's chip rows must start on a row of their own
+            }
             hsw_frame_shape fs;
             rc = hsw_frame_query(&s, b, is_input_range_check ? 1 : 0, &fs);
             if (rc == HSW_OK && fs.n_blocks == 0) rc = HSW_ERR_UNSUPPORTED;
@@ -309,6 +315,7 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
 
 int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint64_t rows) {
     if (!whole || blocks_done != 0 || gate_cursor != 0) return HSW_ERR_INVALID_ARG;
+    if (independent) return HSW_ERR_UNSUPPORTED;         // K regions in one stream: linear only
     const uint64_t G = shape.gate_cells_per_block;
     if (rows < G + 16) return HSW_ERR_INVALID_ARG;        // keeps a block inside <= 2 columns (kernel: <= 2 breaks per block)
     if (origin_row >= rows) return HSW_ERR_INVALID_ARG;   // the Context's next free row lies inside its column
@@ -376,6 +383,7 @@ void Context::position(uint64_t cell, uint64_t *column, uint64_t *row) const {
 
 int Context::set_origin(uint64_t column, uint64_t row, bool zero_cell_loaded, uint64_t lookups_queued) {
     if (!whole || blocks_done != 0 || gate_cursor != 0 || lookup_cursor != origin_lookups) return HSW_ERR_INVALID_ARG;
+    if (independent) return HSW_ERR_UNSUPPORTED;
     if (max_rows && row >= max_rows) return HSW_ERR_INVALID_ARG;
     if (lookups_queued != origin_lookups) {
         // the lookup-advice stream is indexed from the Context's first queued cell: [0, lookups_queued) are the caller's
@@ -543,7 +551,7 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                 r.prologue_cell = d.prologue_cell = gc;      gc += fss[i].prologue_cells;
                 r.prologue_lookup = d.prologue_lookup = lc;  lc += fss[i].prologue_lookups;
                 d.zero_cell = ~0ull;
-                if (!zero_loaded) { d.zero_cell = gc++; zero_loaded = true; }   // compression.rs:34 of the first block
+                if (!zero_loaded || ctx.independent) { d.zero_cell = gc++; zero_loaded = true; }   // compression.rs:34 of the first block of a Context
                 r.block_cell = gc;                           gc += (uint64_t)d.n_blocks * G;
                 r.block_lookup = lc;                         lc += (uint64_t)d.n_blocks * LK;
                 r.epilogue_cell = d.epilogue_cell = gc;      gc += fss[i].epilogue_cells;
@@ -572,7 +580,9 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
                 a.d_lookup = static_cast<uint8_t *>(ctx.d_lookup) + (size_t)results[i].block_lookup * cb;
                 a.flags = ctx.repr_flags;
                 a.frame_every = nb;
-                a.frame_cells = fss[i].epilogue_cells + fss[i].prologue_cells;
+                // (between the block streams of two digests: one epilogue, the next prologue -- and the next Context's
+                //  zero cell when every digest is a Context of its own)
+                a.frame_cells = fss[i].epilogue_cells + fss[i].prologue_cells + (ctx.independent ? 1u : 0u);
                 a.frame_lookups = fss[i].epilogue_lookups + fss[i].prologue_lookups;
                 hsw_pack_plan plan{};
                 if (ctx.max_rows) {
@@ -700,7 +710,8 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                          int is_input_range_check, uint32_t flags, hsw_gadget **out) try {
     if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
-    if (flags & ~HSW_GADGET_WHOLE_DIGEST) return HSW_ERR_INVALID_ARG;
+    if (flags & ~(HSW_GADGET_WHOLE_DIGEST | HSW_GADGET_INDEPENDENT)) return HSW_ERR_INVALID_ARG;
+    if ((flags & HSW_GADGET_INDEPENDENT) && !(flags & HSW_GADGET_WHOLE_DIGEST)) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
     int rc = hsw_engine_shape(e, &s);
@@ -710,7 +721,7 @@ int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, s
     std::vector<size_t> sizes(max_variable_byte_sizes, max_variable_byte_sizes + n_hashes);
     rc = hsw::Sha256DynamicConfig::configure(sizes, s.num_bits_lookup, s.num_advice_columns,
                                              is_input_range_check != 0, &g->cfg);
-    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0);
+    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0, (flags & HSW_GADGET_INDEPENDENT) != 0);
     if (rc != HSW_OK) { delete g; return rc; }
     *out = g;
     return HSW_OK;
@@ -999,7 +1010,7 @@ int hsw_gadget_seek(hsw_gadget *g, size_t hash_idx) try {
             hsw_frame_shape fs;
             rc = hsw_frame_query(&c.shape, b, g->cfg.is_input_range_check ? 1 : 0, &fs);
             if (rc != HSW_OK) return rc;
-            gate += fs.digest_cells + (h == 0 && !c.origin_zero_loaded ? 1 : 0);   // + the Context's zero cell, loaded by digest #0
+            gate += fs.digest_cells + (c.independent || (h == 0 && !c.origin_zero_loaded) ? 1 : 0);   // + the Context's zero cell, loaded by digest #0
             lookup += fs.digest_lookups;
         }
     }
@@ -1070,7 +1081,7 @@ int hsw_gadget_verify(hsw_gadget *g, hsw_verify_report *report) try {
             a.chip_col_stride = c.chip_col_stride;
             a.d_next_states = c.d_next_states + 8 * fb;
             a.d_lookup = static_cast<uint8_t *>(c.d_lookup) + (size_t)r0.block_lookup * cb;
-            a.frame_every = nb; a.frame_cells = fs.epilogue_cells + fs.prologue_cells;
+            a.frame_every = nb; a.frame_cells = fs.epilogue_cells + fs.prologue_cells + (c.independent ? 1u : 0u);
             a.frame_lookups = fs.epilogue_lookups + fs.prologue_lookups;
             a.flags = b.repr_flags;
             hsw_pack_plan rel{};

@@ -74,7 +74,7 @@ class Sha256DynamicConfig {
 
     // lib.rs:351-360: a context sized for every hash this config will assign.
     // whole_digest: also lay out digest()'s own cells (HSW_GADGET_WHOLE_DIGEST)
-    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false) const;
+    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false, bool independent = false) const;
 
     // lib.rs:71-349.  precomputed_input_len = 0 is the reference's None.
     int digest(Context &ctx, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
@@ -121,6 +121,7 @@ class Context {
     // HSW_GADGET_WHOLE_DIGEST: d_gate is one stream (prologue | zero cell | blocks | epilogue per
     // digest, back to back) and d_lookup the lookup-advice stream next to it
     bool whole = false;
+    bool independent = false;        // HSW_GADGET_INDEPENDENT: every digest is a Context of its own (K proofs in flight)
     bool zero_loaded = false;        // Context.zero_cell (first load_zero: compression.rs:34 of the first block)
     uint64_t gate_cursor = 0, gate_capacity = 0;       // cells
     void *d_lookup = nullptr;

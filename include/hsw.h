@@ -522,6 +522,16 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
  * HSW_MODE_HALO2_INTERNALS): the gadget's gate stream is then every advice cell the
  * reference's digest() calls allocate, in allocation order. */
 #define HSW_GADGET_WHOLE_DIGEST 1u
+/* With HSW_GADGET_WHOLE_DIGEST: every digest of the gadget is a synthesis OF ITS OWN -- K proofs of one circuit in
+ * flight (the reference's bench circuit is one digest per proof, benches/digest.rs:93-129): each digest gets a
+ * fresh Context (its own [Constant(0)] cell, A4-iii; its lookup entries and chip rows start at 0 of its own
+ * columns), and hsw_gadget_digest_batch still expands all of them in ONE launch.  The K regions lie back to back
+ * in the gadget's streams: digest h's gate cells are [prologue_cell, end_cell) and its lookup entries
+ * [prologue_lookup, epilogue_lookup + 64) of hsw_hash_result -- cell for cell what a single-digest gadget writes
+ * from cell 0 -- and its chip rows are rows [first_block * limb_calls_per_block / ncols, ...) of the chip columns
+ * (needs n_blocks * limb_calls_per_block to be a multiple of num_advice_columns: HSW_ERR_UNSUPPORTED otherwise).
+ * Linear streams only: hsw_gadget_set_columns / hsw_gadget_set_origin return HSW_ERR_UNSUPPORTED. */
+#define HSW_GADGET_INDEPENDENT  2u
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                          int is_input_range_check, uint32_t flags, hsw_gadget **out);
 void hsw_gadget_destroy(hsw_gadget *g);

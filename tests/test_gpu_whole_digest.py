@@ -491,3 +491,43 @@ def test_compact_delivery_of_a_whole_region(hsw, oracle, eng_int, columns):
         with pytest.raises(hsw.HswError):
             cfg.download_region_compact(bufs)
         cfg.close()
+
+
+@pytest.mark.parametrize("k,mont", [(8, False), (8, True), (9, True)], ids=["K8", "K8-montgomery", "K9-two-launch-path"])
+def test_k_independent_syntheses_of_the_bench_circuit_in_one_batch(hsw, oracle, eng_int, k, mont):
+    """HSW_GADGET_INDEPENDENT: K proofs of the reference's bench circuit (one 16-block digest each,
+    benches/digest.rs:93-129) in flight -- one hsw_gadget_digest_batch call (K = 8: 128 blocks + 8 frames in ONE
+    launch), every digest a Context of its own: its slice of the streams is cell for cell what a fresh
+    single-digest gadget writes (own zero cell, lookup entries and chip rows from 0)."""
+    N = hsw._native
+    rng = np.random.default_rng(0xB0 + k)
+    msgs = [bytes([1] * 56)] + [rng.integers(0, 256, int(rng.integers(0, 1016)), dtype=np.uint8).tobytes() for _ in range(k - 1)]
+    cfg = hsw.Sha256DynamicConfig(eng_int, [1024] * k, is_input_range_check=True, whole_digest=True, independent=True)
+    if mont:
+        cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    with pytest.raises(hsw.HswError):
+        cfg.set_columns((1 << 17) - 9)                       # K regions in one stream: linear only
+    res = cfg.digest_batch(msgs)
+    assert eng_int.last_launch()["split"] == (2 if k * 16 <= 128 else 0)
+    rep = cfg.verify()
+    assert rep["violations"] == 0, rep
+    st = cfg.streams()
+    v = cfg.view()
+    assert int(v.gate_cells) == k * 1116315 == int(v.gate_capacity) and int(v.lookup_cells) == k * 53059
+    conv = oracle.to_montgomery if mont else (lambda x: x)
+    rows_per = 16 * 4120 // 2
+    for h in (0, 1, k - 1):
+        one = oracle.digest_cells([msgs[h]], [1024], None, True)
+        r = res[h]
+        assert r.output_bytes == hashlib.sha256(msgs[h]).digest()
+        assert r.end_cell - r.prologue_cell == len(one["gate"]) == 1116315 and r.prologue_cell == h * 1116315
+        assert r.block_cell == r.prologue_cell + one["layouts"][0]["prologue_cells"] + 1      # its own zero cell
+        assert np.array_equal(st["gate"][r.prologue_cell: r.end_cell], conv(one["gate"]))
+        assert np.array_equal(st["lookup"][r.prologue_lookup: r.prologue_lookup + 53059], conv(one["lookup"]))
+        row0 = r.first_block * 4120 // 2
+        assert np.array_equal(st["dense"][:, row0: row0 + rows_per], conv(one["dense"]))
+        assert np.array_equal(st["spread"][:, row0: row0 + rows_per], conv(one["spread"]))
+    cfg.reset()
+    res2 = cfg.digest_batch(msgs[::-1])                      # next round of proofs on the same buffers
+    assert [r.output_bytes for r in res2] == [hashlib.sha256(m).digest() for m in msgs[::-1]]
+    cfg.close()
