@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: ~6.0-6.3 TB/s is what a streaming kernel reaches on this part
 IV = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
                0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
 
@@ -896,8 +897,15 @@ def run_rank(args):
         assert dig == hashlib.sha256(msgs[i].tobytes()).digest(), "GPU digest mismatch"
 
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    # every rank's own kernel time (HIP events on its launch stream), gathered with one collective of a float each:
+    # an 8-GPU line then shows a straggler instead of hiding it in the max-over-ranks step time
+    kms = torch.tensor([kernel_ms_avg], dtype=torch.float64, device=coll_dev)
+    kms_all = [kms]
     if distributed:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        kms_all = [torch.zeros_like(kms) for _ in range(world)]
+        dist.all_gather(kms_all, kms)
+    kernel_ms_per_rank = [float(t.item()) for t in kms_all]
     elapsed = float(t_el.item())
     total_blocks = n * world * args.steps
     value = total_blocks / elapsed
@@ -934,7 +942,7 @@ def run_rank(args):
         achieved = alg_bytes * n / (kernel_ms_avg * 1e-3) / 1e9
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(path):
                     continue
@@ -974,9 +982,16 @@ def run_rank(args):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                "achievable": HBM_ACHIEVABLE_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "calibrated_fill_GBps": fill_gbs,
+                "calibrated_fill_note": "hsw_fill_calibrate on the same gate buffer: every wave streams its own contiguous 64 KiB "
+                                        "chunks, the best pure-write pattern found on this part (tools/fillbench)",
+                "kernel_ms_per_rank": {"min": min(kernel_ms_per_rank), "max": max(kernel_ms_per_rank), "ranks": kernel_ms_per_rank},
+                "frac_per_rank": {"min": alg_bytes * n / (max(kernel_ms_per_rank) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "max": alg_bytes * n / (min(kernel_ms_per_rank) * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "kernel": "%s, %d waves per block%s" % (launched["kernel"], launched["parts"],
                                                          ", split phases" if launched["split"] else ""),
                 "launch": launched,

@@ -53,11 +53,17 @@ __global__ __launch_bounds__(64) void hsw_chain_var_kernel(const uint8_t *blocks
                   init_states ? init_states + 8 * m : nullptr, pre_states);
 }
 
-// Plain streaming fill, 16 B per lane, grid-stride: the practical HBM write
-// ceiling the expand kernel is compared against (bench.py "calibrated").
-__global__ __launch_bounds__(256) void hsw_fill_kernel(uint4 *dst, size_t n16, uint4 v) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = v;
+// Calibration fill: every wave streams its own contiguous 64 KiB chunks, 16 B per lane -- the best pure-write pattern
+// found on this part (tools/fillbench: 5.7-5.8 TB/s on a 9.77 GB buffer; a grid-stride fill reaches 4.9-5.3).  What
+// bench.py reports as `roofline.calibrated_fill_GBps`, next to the 8 TB/s spec and the guide's ~6.3 TB/s achievable.
+__global__ __launch_bounds__(64) void hsw_fill_kernel(uint4 *dst, size_t n16, uint4 v) {
+    constexpr size_t CHUNK = 4096;                       // 16-byte pieces per chunk (64 KiB)
+    const size_t nwaves = gridDim.x;
+    for (size_t c = blockIdx.x; c * CHUNK < n16; c += nwaves) {
+        const size_t base = c * CHUNK;
+        const size_t end = base + CHUNK < n16 ? base + CHUNK : n16;
+        for (size_t i = base + threadIdx.x; i < end; i += 64) dst[i] = v;
+    }
 }
 
 // Compact transport of a finished region (hsw.h hsw_gadget_download_region_compact): cell i of a 32-byte
@@ -96,7 +102,7 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;
     uint4 v; v.x = 0x01010101u; v.y = 0; v.z = 0; v.w = 0;
-    hipLaunchKernelGGL(hsw_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<uint4 *>(dst), n16, v);
+    hipLaunchKernelGGL(hsw_fill_kernel, dim3(256 * 16), dim3(64), 0, stream, reinterpret_cast<uint4 *>(dst), n16, v);
     return hipGetLastError();
 }
 

@@ -72,3 +72,21 @@ def test_launcher_starts_one_child_per_rank(tmp_path, monkeypatch):
     calls.clear()
     fail_rank[0] = 1
     assert bench.launch_ranks(A, ["--gpus", "3"]) != 0
+
+
+def test_gpus_8_with_one_visible_gpu_exits_2_with_the_message(monkeypatch, capsys):
+    """The driver's 8-GPU run on a box that shows one GPU must not degrade to a 1-GPU line: exit code 2 and a
+    message, no rank started."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    started = []
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, **k: started.append(a))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("HSW_BENCH_SAME_DEVICE", raising=False)
+
+    class A:
+        gpus = 8
+    assert bench.launch_ranks(A, ["--gpus", "8"]) == 2
+    assert started == []
+    assert "--gpus 8 asked for, but only 1 GPU(s) visible" in capsys.readouterr().err
