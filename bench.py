@@ -550,6 +550,47 @@ def extra_config0(hsw, local_rank, with_cpu):
             "verify_on_device": {"violations": vm["violations"], "checks": vm["checks"]},
             "note": "the same synthesis with cells in Montgomery form (x * 2^256 mod p, halo2curves' in-memory Fr): "
                     "the form the Rust shim consumes"}
+        # ... and on to the host as DISTINCT values: only the new witnesses (~40 % of the cells) cross PCIe, the
+        # input-independent tape rebuilds copies and constants on the host (hsw_replay.cpp)
+        try:
+            tape = hsw._native.RegionTape()
+            assert L.hsw_gadget_region_tape(cfgm.h, C.byref(tape)) == 0
+            himg = cfgm.download_region(pinned=True)                 # the 32-byte delivery, as the reference image
+            dbuf = eng_i.host_empty((int(tape.distinct_capacity), 4))
+            rgate, rlook = eng_i.host_empty(himg["gate"].shape), eng_i.host_empty(himg["lookup"].shape)
+            rgate[:] = 0
+            rdst = hsw._native.RegionHost(rgate.ctypes.data, rlook.ctypes.data, None, None)
+            nd = C.c_size_t()
+            threads = min(16, host_cores())
+            t_full, t_dist, t_rep = [], [], []
+            fdst = hsw._native.RegionHost(himg["gate"].ctypes.data, himg["lookup"].ctypes.data, None, None)
+            for _ in range(9):
+                assert L.hsw_gadget_reset(cfgm.h) == 0
+                t1 = time.perf_counter()
+                assert L.hsw_gadget_digest(cfgm.h, mbuf, 56, 0, C.byref(hres)) == 0
+                assert L.hsw_gadget_download_region(cfgm.h, C.byref(fdst)) == 0
+                t_full.append(time.perf_counter() - t1)
+                assert L.hsw_gadget_reset(cfgm.h) == 0
+                t1 = time.perf_counter()
+                assert L.hsw_gadget_digest(cfgm.h, mbuf, 56, 0, C.byref(hres)) == 0
+                assert L.hsw_gadget_download_region_distinct(cfgm.h, dbuf.ctypes.data, dbuf.shape[0], C.byref(nd)) == 0
+                t2 = time.perf_counter()
+                assert L.hsw_gadget_replay_region(cfgm.h, dbuf.ctypes.data, C.byref(rdst), threads) == 0
+                t3 = time.perf_counter()
+                t_dist.append(t2 - t1)
+                t_rep.append(t3 - t2)
+            assert np.array_equal(rgate, himg["gate"]) and np.array_equal(rlook, himg["lookup"]), "replayed region differs from the 32-byte delivery"
+            res["whole_region_montgomery_to_host"] = {
+                "full_32_byte_cells_ms": float(np.median(t_full)) * 1e3, "full_bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
+                "distinct_ms": float(np.median(t_dist)) * 1e3, "distinct_cells": int(nd.value), "distinct_bytes": int(nd.value) * 32,
+                "replay_ms": float(np.median(t_rep)) * 1e3, "replay_threads": threads,
+                "distinct_plus_replay_ms": float(np.median(np.array(t_dist) + np.array(t_rep))) * 1e3,
+                "note": "synthesis + hsw_gadget_download_region_distinct (the new witnesses only, Montgomery form, pinned memory); "
+                        "hsw_gadget_replay_region rebuilds gate image + lookup column on the host (checked bit-equal to the "
+                        "32-byte delivery here); a consumer that walks the region cell by cell reads value(code[i]) through "
+                        "the tape instead and needs no replay"}
+        except Exception as ex:
+            res["whole_region_montgomery_to_host"] = {"error": repr(ex)}
         cfgm.close()
     except Exception as ex:
         res["whole_region_montgomery"] = {"error": repr(ex)}
@@ -719,9 +760,39 @@ def extra_config4_substitute(hsw, eng, local_rank, blocks_h, pre_h, alg_bytes):
             cfg.digest_batch(msgs)
             assert eng_i.lib.hsw_gadget_download_region(cfg.h, C.byref(dst)) == 0
             td.append(time.perf_counter() - t1)
+        # the same region as distinct values in Montgomery form (what a halo2 prover takes): new witnesses only
+        distinct = None
+        try:
+            cfg.reset()
+            cfg.set_repr(hsw._native.HSW_REPR_MONTGOMERY)
+            cfg.digest_batch(msgs)
+            tape = hsw._native.RegionTape()
+            assert eng_i.lib.hsw_gadget_region_tape(cfg.h, C.byref(tape)) == 0
+            dbuf = eng_i.host_empty((int(tape.distinct_capacity), 4))
+            nd = C.c_size_t()
+            tdd, tdf = [], []
+            for _ in range(5):
+                cfg.reset()
+                t1 = time.perf_counter()
+                cfg.digest_batch(msgs)
+                assert eng_i.lib.hsw_gadget_download_region_distinct(cfg.h, dbuf.ctypes.data, dbuf.shape[0], C.byref(nd)) == 0
+                tdd.append(time.perf_counter() - t1)
+                cfg.reset()
+                t1 = time.perf_counter()
+                cfg.digest_batch(msgs)
+                assert eng_i.lib.hsw_gadget_download_region(cfg.h, C.byref(dst)) == 0
+                tdf.append(time.perf_counter() - t1)
+            distinct = {"montgomery_full_ms": float(np.median(tdf)) * 1e3, "montgomery_distinct_ms": float(np.median(tdd)) * 1e3,
+                        "distinct_cells": int(nd.value), "distinct_bytes": int(nd.value) * 32}
+            cfg.reset()
+            cfg.set_repr(hsw._native.HSW_REPR_CANONICAL)
+            cfg.digest_batch(msgs)
+        except Exception as ex:
+            distinct = {"error": repr(ex)}
         vrep = cfg.verify()
         nbytes = (int(v.gate_cells) + int(v.lookup_cells) + 2 * int(v.num_limb_sum)) * 32
         res["whole_region_k20"] = {
+            "to_host_as_distinct_values": distinct,
             "digests": len(sizes), "blocks": sum(sizes) // 64, "advice_columns": ncol, "max_rows": (1 << 20) - 9,
             "gate_cells": int(v.gate_cells), "lookup_cells": int(v.lookup_cells),
             "synthesis_ms": float(np.median(ts)) * 1e3, "synthesis_GBps": nbytes / float(np.median(ts)) / 1e9,

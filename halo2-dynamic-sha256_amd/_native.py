@@ -149,6 +149,16 @@ class RegionHost(C.Structure):
     _fields_ = [("gate", C.c_void_p), ("lookup", C.c_void_p), ("chip_dense", C.c_void_p), ("chip_spread", C.c_void_p)]
 
 
+class RegionTape(C.Structure):
+    _fields_ = [("n_distinct", C.c_uint64), ("distinct_capacity", C.c_uint64), ("gate_cells", C.c_uint64),
+                ("lookup_cells", C.c_uint64), ("limb_calls", C.c_uint64), ("gate_code", C.POINTER(C.c_uint32)),
+                ("lookup_code", C.POINTER(C.c_uint32)), ("chip_dense_code", C.POINTER(C.c_uint32)),
+                ("chip_spread_code", C.POINTER(C.c_uint32)), ("consts", C.c_void_p), ("n_consts", C.c_uint64)]
+
+
+HSW_TAPE_CONST = 0x80000000
+
+
 class GadgetView(C.Structure):
     _fields_ = [("d_gate", C.c_void_p), ("d_chip_dense", C.c_void_p), ("d_chip_spread", C.c_void_p),
                 ("d_next_states", C.c_void_p), ("chip_col_stride", C.c_size_t), ("blocks_done", C.c_size_t),
@@ -176,7 +186,7 @@ SYMBOLS = (
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
     "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
     "hsw_gadget_download_region_compact", "hsw_region_widen", "hsw_gadget_result_cells",
-    "hsw_gadget_set_origin",
+    "hsw_gadget_set_origin", "hsw_gadget_region_tape", "hsw_gadget_download_region_distinct", "hsw_gadget_replay_region",
 )
 
 
@@ -290,6 +300,12 @@ def lib():
                                          C.POINTER(PackPlan), C.c_uint32]
         L.hsw_gadget_set_columns.restype = C.c_int
         L.hsw_gadget_set_columns.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.hsw_gadget_region_tape.restype = C.c_int
+        L.hsw_gadget_region_tape.argtypes = [vp, C.POINTER(RegionTape)]
+        L.hsw_gadget_download_region_distinct.restype = C.c_int
+        L.hsw_gadget_download_region_distinct.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.hsw_gadget_replay_region.restype = C.c_int
+        L.hsw_gadget_replay_region.argtypes = [vp, vp, C.POINTER(RegionHost), C.c_uint]
         L.hsw_gadget_set_origin.restype = C.c_int
         L.hsw_gadget_set_origin.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.hsw_verify_frames.restype = C.c_int

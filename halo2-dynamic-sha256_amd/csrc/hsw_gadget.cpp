@@ -677,11 +677,6 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
 }  // namespace hsw
 
 // ------------------------------------------------------------------- C ABI
-struct hsw_gadget {
-    hsw::Sha256DynamicConfig cfg;
-    hsw::Context *ctx = nullptr;
-    std::vector<hsw::AssignedHashResult> results;   // one per digest so far (input_bytes kept for queries)
-};
 
 extern "C" {
 
@@ -827,6 +822,7 @@ int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns
     int rc = hsw_engine_synchronize(g->ctx->engine);          // the image is reallocated: nothing may still write the old one
     if (rc == HSW_OK) rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
     if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
+    if (rc == HSW_OK) { hsw::free_region_tape(g->tape); g->tape = nullptr; }     // positions follow the layout
     return rc;
 } HSW_NO_UNWIND
 
@@ -840,6 +836,8 @@ int hsw_gadget_set_origin(hsw_gadget *g, uint64_t column, uint64_t row, int zero
     const uint64_t old[4] = {c.origin_column, c.origin_row, c.origin_zero_loaded ? 1u : 0u, c.origin_lookups};
     rc = c.set_origin(column, row, zero_cell_loaded != 0, lookups_already_queued);
     if (rc != HSW_OK) return rc;
+    hsw::free_region_tape(g->tape);                        // zero cell and positions follow the origin
+    g->tape = nullptr;
     if (c.max_rows && (old[1] != row || old[2] != (zero_cell_loaded ? 1u : 0u))) {
         // the column breaks follow from where the stream starts: lay the image out again
         rc = c.set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, c.max_rows);

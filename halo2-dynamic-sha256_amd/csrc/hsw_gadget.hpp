@@ -156,5 +156,18 @@ class Context {
     void free_compact_staging();                       // the 8-byte staging follows the geometry: dropped when it changes
 };
 
+// The input-independent half of a whole region (hsw_replay.cpp): which cells are NEW witnesses, and for every other
+// cell of the gate / lookup / chip streams which witness or constant it repeats.
+struct RegionTape;
+void free_region_tape(RegionTape *t);
+
 }  // namespace hsw
+
+struct hsw_gadget {
+    hsw::Sha256DynamicConfig cfg;
+    hsw::Context *ctx = nullptr;
+    std::vector<hsw::AssignedHashResult> results;   // one per digest so far (input_bytes kept for queries)
+    hsw::RegionTape *tape = nullptr;                // built on first use, dropped when the layout changes
+    ~hsw_gadget() { hsw::free_region_tape(tape); }
+};
 #endif

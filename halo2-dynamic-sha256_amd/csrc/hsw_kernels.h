@@ -71,6 +71,9 @@ hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream);
 hipError_t launch_pack64(const void *src32, void *dst8, size_t n_cells, uint64_t stream_id, uint64_t index0,
                          void *wide, uint32_t wide_cap, uint32_t *wide_count, hipStream_t stream);
 
+// dst[w] = the 32-byte cell at image position pos[w] (distinct-value delivery, hsw_replay.cpp)
+hipError_t launch_gather32(const void *image, const uint32_t *pos, void *dst, size_t n, hipStream_t stream);
+
 struct FrameDesc;   // hsw_frame.hpp
 struct FrameBreaks;
 struct SmallFrames;

@@ -98,6 +98,21 @@ hipError_t launch_pack64(const void *src32, void *dst8, size_t n_cells, uint64_t
     return hipGetLastError();
 }
 
+// Distinct-value delivery (hsw_replay.cpp): lane pairs fetch the two halves of the new-witness cells of a region,
+// in stream order -- consecutive witnesses are a few cells apart, so the reads stay within a few lines.
+__global__ __launch_bounds__(256) void hsw_gather32_kernel(const uint4 *img, const u32 *pos, uint4 *dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride)
+        dst[i] = img[2 * (size_t)pos[i >> 1] + (i & 1)];
+}
+hipError_t launch_gather32(const void *image, const uint32_t *pos, void *dst, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t want = (2 * n + 255) / 256;
+    hipLaunchKernelGGL(hsw_gather32_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(image), pos, reinterpret_cast<uint4 *>(dst), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(void *dst, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;

@@ -152,6 +152,32 @@ class Sha256DynamicConfig:
             out["lookup"] = lookup[: int(v.lookup_cells)]
         return out
 
+    def download_region_distinct(self, threads=8, bufs=None):
+        """Distinct-value delivery: only the new witnesses cross PCIe (hsw_gadget_download_region_distinct into
+        pinned memory), the image is rebuilt on the host (hsw_gadget_replay_region).  Returns the same dict as
+        download_region plus "distinct" (n, 4) and "bufs" (pass back in to reuse the host buffers)."""
+        import numpy as np
+        tape = N.RegionTape()
+        self._ok(self.lib.hsw_gadget_region_tape(self.h, C.byref(tape)))
+        v = self.view()
+        ncols = self.engine.ncols
+        img = int(v.max_rows)
+        n_gate = int(v.max_rows) * int(v.columns) if img else int(v.gate_cells)
+        stride = int(v.chip_col_stride)
+        if bufs is None:          # sized for the whole gadget, so that they can be reused as more digests are assigned
+            bufs = dict(distinct=self.engine.host_empty((max(int(tape.distinct_capacity), 1), 4)),
+                        gate=np.zeros((max(n_gate if img else int(v.gate_capacity), 1), 4), dtype=np.uint64), lookup=np.zeros((max(int(v.lookup_capacity), 1), 4), dtype=np.uint64),
+                        dense=np.zeros((ncols * stride, 4), dtype=np.uint64), spread=np.zeros((ncols * stride, 4), dtype=np.uint64))
+        n = C.c_size_t()
+        self._ok(self.lib.hsw_gadget_download_region_distinct(self.h, bufs["distinct"].ctypes.data, bufs["distinct"].shape[0], C.byref(n)))
+        dst = N.RegionHost(bufs["gate"].ctypes.data, bufs["lookup"].ctypes.data, bufs["dense"].ctypes.data, bufs["spread"].ctypes.data)
+        self._ok(self.lib.hsw_gadget_replay_region(self.h, bufs["distinct"].ctypes.data, C.byref(dst), threads))
+        rows = (int(v.num_limb_sum) + ncols - 1) // ncols
+        return dict(gate=bufs["gate"][:n_gate].reshape(int(v.columns), int(v.max_rows), 4) if img else bufs["gate"][:n_gate],
+                    lookup=bufs["lookup"][: int(v.lookup_cells)], dense=bufs["dense"].reshape(ncols, stride, 4)[:, :rows],
+                    spread=bufs["spread"].reshape(ncols, stride, 4)[:, :rows], rows=rows, distinct=bufs["distinct"][: n.value],
+                    n_distinct=int(n.value), bufs=bufs)
+
     def download_region_compact(self, bufs=None):
         """hsw_gadget_download_region_compact into pinned host arrays: 8-byte cells + the side list of the cells
         wider than 64 bits.  Returns (bufs, n_wide); pass `bufs` back in to reuse the buffers.  widen() rebuilds

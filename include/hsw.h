@@ -611,6 +611,39 @@ int hsw_gadget_download_region_compact(hsw_gadget *g, hsw_region_compact *dst);
  * (indices relative to the same buffer) copied over them. */
 int hsw_region_widen(const uint64_t *compact, size_t n_cells, uint64_t stream_id, const hsw_wide_cell *wide,
                      size_t n_wide, void *cells32);
+/* ---- distinct-value delivery of a whole region (HSW_GADGET_WHOLE_DIGEST contexts, 32-byte cells) ----
+ * About 60 % of a region's cells repeat an earlier cell (QuantumCell::Existing, lookup-column copies, the
+ * spread-chip cells tied to gate cells: spread.rs:209-210,226-227) or hold a gate constant, at positions that do not
+ * depend on the input.  So only the NEW witnesses need to cross PCIe:
+ *   hsw_gadget_region_tape              the input-independent half, built once per layout on the host: for every
+ *                                       cell of the gate / lookup / chip streams assigned so far either
+ *                                       HSW_TAPE_CONST | k (consts[k]) or the index of a distinct value -- copy
+ *                                       chains already resolved, so cell i is simply  value(code[i])
+ *   hsw_gadget_download_region_distinct packs the distinct values on the device (one gather launch) and copies
+ *                                       them to `distinct` (cap_cells 32-byte cells, ideally pinned: hsw_host_alloc),
+ *                                       in the gadget's representation (Montgomery for a halo2 prover)
+ *   hsw_gadget_replay_region            rebuilds what hsw_gadget_download_region delivers -- column image (or
+ *                                       linear stream), lookup column, chip columns; layouts and the
+ *                                       "never touch the caller's cells" rules as there -- from the distinct
+ *                                       values, with `threads` host threads (pure host work; a consumer that
+ *                                       walks the region cell by cell anyway can read value(code[i]) itself)
+ * The tape pointers stay valid until the layout changes (hsw_gadget_set_columns / _set_origin) or the gadget
+ * is destroyed.  HSW_ERR_TOO_LARGE: cap_cells too small (*n_cells says how many), or a region of 2^30 cells or more. */
+#define HSW_TAPE_CONST 0x80000000u
+typedef struct hsw_region_tape {
+    uint64_t n_distinct;                 /* distinct values of the digests assigned so far in this pass */
+    uint64_t distinct_capacity;          /* ... of all digests of the gadget: size a reusable buffer with this */
+    uint64_t gate_cells, lookup_cells, limb_calls;   /* entries of the code arrays that are assigned so far */
+    const uint32_t *gate_code;           /* per gate-stream cell (hsw_gadget_cell_position gives its column / row) */
+    const uint32_t *lookup_code;         /* per lookup entry of the gadget (entry j sits at d_lookup cell origin_lookups + j) */
+    const uint32_t *chip_dense_code, *chip_spread_code;   /* per limb call n: column n % ncols, row n / ncols */
+    const void *consts;                  /* n_consts 32-byte cells in the gadget's current representation */
+    uint64_t n_consts;
+} hsw_region_tape;
+int hsw_gadget_region_tape(hsw_gadget *g, hsw_region_tape *out);
+int hsw_gadget_download_region_distinct(hsw_gadget *g, void *distinct, size_t cap_cells, size_t *n_cells);
+int hsw_gadget_replay_region(hsw_gadget *g, const void *distinct, const hsw_region_host *dst, unsigned threads);
+
 /* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
  * (cur_hash_idx, num_limb_sum, the gate / lookup stream cursors, the zero cell) takes the value it
  * would have then.  All of them follow from max_variable_byte_sizes alone -- never from the

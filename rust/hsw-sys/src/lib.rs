@@ -278,6 +278,22 @@ pub struct hsw_region_host {
     pub chip_spread: *mut c_void,
 }
 
+pub const HSW_TAPE_CONST: u32 = 0x8000_0000;
+#[repr(C)]
+pub struct hsw_region_tape {
+    pub n_distinct: u64,
+    pub distinct_capacity: u64,
+    pub gate_cells: u64,
+    pub lookup_cells: u64,
+    pub limb_calls: u64,
+    pub gate_code: *const u32,
+    pub lookup_code: *const u32,
+    pub chip_dense_code: *const u32,
+    pub chip_spread_code: *const u32,
+    pub consts: *const c_void,
+    pub n_consts: u64,
+}
+
 #[repr(C)]
 pub struct hsw_gadget_view {
     pub d_gate: *mut c_void,
@@ -359,6 +375,12 @@ extern "C" {
                                 is_input_range_check: c_int, flags: u32, out: *mut *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_destroy(g: *mut hsw_gadget);
     pub fn hsw_gadget_set_columns(g: *mut hsw_gadget, max_rows: u64, n_columns: *mut u64) -> c_int;
+    /// Distinct-value delivery: the input-independent tape, the packed new witnesses, the host replay.
+    pub fn hsw_gadget_region_tape(g: *mut hsw_gadget, out: *mut hsw_region_tape) -> c_int;
+    pub fn hsw_gadget_download_region_distinct(g: *mut hsw_gadget, distinct: *mut c_void, cap_cells: usize,
+                                               n_cells: *mut usize) -> c_int;
+    pub fn hsw_gadget_replay_region(g: *mut hsw_gadget, distinct: *const c_void, dst: *const hsw_region_host,
+                                    threads: u32) -> c_int;
     /// Where the caller's `Context` stands: `ctx.advice_alloc[0]`, `ctx.zero_cell.is_some()`, `ctx.cells_to_lookup.len()`.
     pub fn hsw_gadget_set_origin(g: *mut hsw_gadget, column: u64, row: u64, zero_cell_loaded: c_int,
                                  lookups_already_queued: u64) -> c_int;

@@ -95,6 +95,20 @@ static void whole_region() {
         CHECK(hsw_gadget_download_region_compact(g, &c) == HSW_OK);
         std::vector<uint64_t> widened(gate_cells * 4);
         CHECK(hsw_region_widen(gate8.data(), gate_cells, HSW_STREAM_GATE, wide.data(), c.n_wide, widened.data()) == HSW_OK);
+        // distinct-value delivery: tape, packed witnesses into an exact-size buffer, replay into exact-size images
+        hsw_region_tape tape;
+        CHECK(hsw_gadget_region_tape(g, &tape) == HSW_OK);
+        CHECK(tape.gate_cells == v.gate_cells && tape.lookup_cells + v.origin_lookups == v.lookup_cells);
+        CHECK(tape.n_distinct > tape.gate_cells / 4 && tape.n_distinct < tape.gate_cells / 2 && tape.n_distinct <= tape.distinct_capacity);
+        for (uint64_t i = 0; i < tape.gate_cells; i++) {
+            const uint32_t code = tape.gate_code[i];
+            CHECK((code & HSW_TAPE_CONST) ? (code & ~HSW_TAPE_CONST) < tape.n_consts : code < tape.n_distinct);
+        }
+        std::vector<uint64_t> distinct(tape.n_distinct * 4);
+        size_t nd = 0;
+        CHECK(hsw_gadget_download_region_distinct(g, distinct.data(), tape.n_distinct - 1, &nd) == HSW_ERR_TOO_LARGE && nd == tape.n_distinct);
+        CHECK(hsw_gadget_download_region_distinct(g, distinct.data(), tape.n_distinct, &nd) == HSW_OK);
+        for (unsigned threads : {1u, 5u}) CHECK(hsw_gadget_replay_region(g, distinct.data(), &dst, threads) == HSW_OK);
         hsw_verify_report rep;
         CHECK(hsw_gadget_verify(g, &rep) == HSW_OK);
         for (size_t h = 0; h < 2; h++) {

@@ -235,3 +235,50 @@ def test_compact_staging_follows_the_geometry(hsw, oracle, eng_int):
     assert np.array_equal(img, full["gate"])
     assert cfg.verify()["violations"] == 0
     cfg.close()
+
+
+@pytest.mark.parametrize("layout", ["linear", "columns", "columns-at-origin", "independent"])
+@pytest.mark.parametrize("mont", [False, True], ids=["canonical", "montgomery"])
+def test_distinct_value_delivery_rebuilds_the_region(hsw, oracle, eng_int, layout, mont):
+    """hsw_gadget_download_region_distinct + hsw_gadget_replay_region: only the new witnesses (~40 % of the cells)
+    cross PCIe; the tape (input independent: copies resolved to their root witness or to a constant) rebuilds the
+    gate image, the lookup column and the chip columns on the host -- bit-equal to hsw_gadget_download_region."""
+    N = hsw._native
+    sizes, msgs = [128, 64, 192], [b"distinct values", b"", bytes(range(150))]
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True, independent=layout == "independent")
+    if mont:
+        cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    if layout.startswith("columns"):
+        cfg.set_columns(100003)
+    if layout == "columns-at-origin":
+        cfg.set_origin(3, 99990, True, 11)                  # the first break a few cells into the first prologue
+    bufs = None
+    for trial, batch in enumerate((msgs[:2], msgs)):        # after two digests, then after all three (and a reset)
+        cfg.digest_batch(batch)
+        full = cfg.download_region(pinned=False)
+        got = cfg.download_region_distinct(threads=1 + 3 * trial, bufs=bufs)
+        bufs = got["bufs"]
+        assert 0.25 < got["n_distinct"] / int(cfg.view().gate_cells) < 0.5
+        assert np.array_equal(got["gate"], full["gate"]), layout
+        lq = int(cfg.view().origin_lookups)
+        assert np.array_equal(got["lookup"][lq:], full["lookup"][lq:])
+        assert np.array_equal(got["dense"], full["dense"]) and np.array_equal(got["spread"], full["spread"])
+        cfg.reset()
+    # the tape alone: every cell is value(code[i])
+    cfg.digest_batch(msgs)
+    tape = N.RegionTape()
+    cfg._ok(cfg.lib.hsw_gadget_region_tape(cfg.h, C.byref(tape)))
+    st = cfg.streams()
+    got = cfg.download_region_distinct(bufs=bufs)
+    code = np.ctypeslib.as_array(tape.gate_code, shape=(int(tape.gate_cells),))
+    consts = np.ctypeslib.as_array(C.cast(tape.consts, C.POINTER(C.c_uint64)), shape=(int(tape.n_consts), 4))
+    is_c = (code & np.uint32(N.HSW_TAPE_CONST)) != 0
+    vals = np.where(is_c[:, None], consts[np.where(is_c, code & np.uint32(0x7fffffff), 0)], got["distinct"][np.where(is_c, 0, code)])
+    if layout.startswith("columns"):
+        lin = np.zeros_like(vals)
+        for i in range(0, len(vals), 4099):                 # a sample of positions through cell_position
+            c_, r_ = cfg.cell_position(i)
+            assert np.array_equal(st["gate"][c_ - int(cfg.view().origin_column), r_], vals[i]), i
+    else:
+        assert np.array_equal(st["gate"], vals)
+    cfg.close()

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "halo2-dynamic-sha256_amd", "csrc")
 SAN = ["-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
        "-fno-omit-frame-pointer", "-Wno-option-ignored"]
-KERNEL_OBJS = ("hsw_kernels.o", "hsw_frame.o", "hsw_verify.o", "hsw_expand_l1.o", "hsw_expand_l2.o", "hsw_expand_l4.o",
+KERNEL_OBJS = ("hsw_kernels.o", "hsw_frame.o", "hsw_verify.o", "hsw_expand_l1.o", "hsw_expand_l2.o", "hsw_expand_l2_m32.o", "hsw_expand_l4.o",
                "hsw_expand_l8.o", "hsw_expand_l16.o", "hsw_expand_l8_rc.o", "hsw_expand_l16_rc.o", "hsw_small_l2.o")
 
 
@@ -41,7 +41,7 @@ def host_objects(tmp_path_factory):
     if not all(os.path.exists(k) for k in kernels):
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     out = str(tmp_path_factory.mktemp("san"))
-    objs = [_compile(hipcc, os.path.join(CSRC, f), out) for f in ("hsw_api.cpp", "hsw_api_region.cpp", "hsw_gadget.cpp")]
+    objs = [_compile(hipcc, os.path.join(CSRC, f), out) for f in ("hsw_api.cpp", "hsw_api_region.cpp", "hsw_gadget.cpp", "hsw_replay.cpp")]
     return hipcc, out, objs, kernels
 
 
