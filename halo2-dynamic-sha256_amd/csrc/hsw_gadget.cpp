@@ -449,12 +449,12 @@ int Sha256DynamicConfig::digest_batch(Context &ctx, size_t n, const uint8_t *con
     // lane.  Either way the witness cells -- and the next_states the digest is read from -- come from the
     // GPU.  Host-chained batches stage blocks and pre-states in pinned, device-mapped host memory.
     // Which side chains: the host walks all blocks at ~0.1 us each (x86 SHA extensions; 0.4 us scalar), the
-    // GPU chains every message on its own lane at ~3.6 us per block plus a dependent launch.  Many short
-    // messages -> GPU; few long ones -> host.
+    // GPU chains every message on its own wave (up to 2,048 messages: ~1.8 us per block) or lane (~3.6 us per
+    // block) plus a dependent launch.  Many short messages -> GPU; few long ones -> host.
     size_t longest = 0;
     for (size_t i = 0; i < n; i++) longest = plans[i].max_variable_round > longest ? plans[i].max_variable_round : longest;
     const double t_host_us = (double)batch_blocks * (host_sha_is_fast() ? 0.1 : 0.4);
-    const double t_gpu_us = 15.0 + 3.6 * (double)longest;
+    const double t_gpu_us = 15.0 + (n <= (size_t)HSW_CHAIN_WAVE_MAX_MESSAGES ? 1.8 : 3.6) * (double)longest;   // a wave / a lane per message
     const bool host_chain = t_host_us <= t_gpu_us;
     const size_t b0 = ctx.blocks_done;
     if (host_chain && batch_blocks) {
