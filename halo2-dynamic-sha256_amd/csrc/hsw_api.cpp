@@ -531,7 +531,7 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
             hsw_launch_info &li = e->last_launch;
             const bool wide_internals = e->mode == HSW_MODE_HALO2_INTERNALS && e->limbs > 2;   // [64][32] tiles only
             li.limbs = (uint32_t)e->limbs;
-            li.tile_cells = m32 ? 16u : wide_internals ? 32u : tile == 6416 ? 64u : (uint32_t)tile;
+            li.tile_cells = m32 ? (uint32_t)hsw::HSW_M32_TILE : wide_internals ? 32u : tile == 6416 ? 64u : (uint32_t)tile;
             li.tile_rows = m32 ? 64u : wide_internals ? 64u : tile == 6416 ? 16u : 2048u / (uint32_t)tile;
             li.repr = m32 ? 3u : (flags & HSW_REPR_MONTGOMERY) ? 1u : (flags & HSW_REPR_COMPACT64) ? 2u : 0u;
             li.internals = e->mode == HSW_MODE_HALO2_INTERNALS ? 1u : 0u;

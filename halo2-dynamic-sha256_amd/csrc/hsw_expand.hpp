@@ -1558,9 +1558,6 @@ hipError_t launch_expand_L_internals_wide(const ExpandParams &p, hipStream_t str
 extern template hipError_t launch_expand_L_internals_wide<8>(const ExpandParams &, hipStream_t);
 extern template hipError_t launch_expand_L_internals_wide<16>(const ExpandParams &, hipStream_t);
 
-#ifndef HSW_M32_TILE
-#define HSW_M32_TILE 8
-#endif
 // Montgomery cells built at emit time (Em::M32): [64 rows][8 cells] tiles of 32-byte cells (20 KiB of LDS: 7 waves per
 // CU), one wave per block.  Built for the reference's 8-bit table, in a translation unit of its own
 // (hsw_expand_l2_m32.hip).

@@ -22,6 +22,7 @@ enum : uint32_t {
                              // finished 32-byte cells (hsw_expand.hpp Em::M32); else one conversion per cell at write-out
 };
 enum { HSW_K_MAX_BREAKS = 16 };
+enum { HSW_M32_TILE = 8 };                     // cells per tile row of the emit-time Montgomery kernels (Em::M32): [64][8] x 32 B = 16 KiB
 enum { HSW_CHAIN_WAVE_MAX_MESSAGES = 2048 };   // chain pre-pass: up to this many messages get a wave each (8 waves per CU), beyond
                                                // that one lane per message has the parallelism anyway
 enum { HSW_SMALL_WAVES_PER_BLOCK = 37 };   // roles of the small-batch kernel (hsw_small.hpp)

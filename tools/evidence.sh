@@ -21,5 +21,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq2 -o s -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq2.json 2> $OUT/sq2.log || exit 1
 python3 tools/profile_extract.py sq $OUT/sq_counters.json $(find $OUT/sq1 -name "*.db" | head -1) $(find $OUT/sq2 -name "*.db" | head -1)
 echo "sq counters done"
-rm -rf $OUT/kt $OUT/pmc_WRITE_SIZE $OUT/pmc_FETCH_SIZE $OUT/sq1 $OUT/sq2
+# the three cell forms of the 4,096-block launch side by side: canonical, Montgomery converted at write-out, Montgomery
+# converted at emit time (tools/mont_once.py: three launches each)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/m1 -o s -- python3 tools/mont_once.py > $OUT/m1.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/m2 -o s -- python3 tools/mont_once.py > $OUT/m2.log 2>&1 || exit 1
+python3 tools/profile_extract.py sq $OUT/sq_counters_montgomery.json $(find $OUT/m1 -name "*.db" | head -1) $(find $OUT/m2 -name "*.db" | head -1)
+rocprofv3 --kernel-trace --stats -d $OUT/m3 -o s -- python3 tools/mont_once.py > $OUT/m3.log 2>&1 || exit 1
+python3 tools/profile_extract.py stats_by_grid $(find $OUT/m3 -name "*.db" | head -1) $OUT/montgomery_kernel_stats.csv 4096
+echo "montgomery counters done"
+rm -rf $OUT/kt $OUT/pmc_WRITE_SIZE $OUT/pmc_FETCH_SIZE $OUT/sq1 $OUT/sq2 $OUT/m1 $OUT/m2 $OUT/m3
 ls -la $OUT
