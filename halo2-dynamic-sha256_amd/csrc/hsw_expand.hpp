@@ -76,7 +76,9 @@ static __device__ __constant__ u32 IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef37
 // phase boundaries.  Never defined in the product build.
 #ifdef HSW_STAMPS
 __device__ unsigned long long *g_hsw_stamps = nullptr;
-#define HSW_STAMP(i) do { if (threadIdx.x == 0 && g_hsw_stamps) g_hsw_stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+// slot 15: where the wave ran -- XCC_ID (hwreg 20) << 32 | HW_ID (hwreg 4: wave, simd, cu, sh, se)
+#define HSW_STAMP(i) do { if (threadIdx.x == 0 && g_hsw_stamps) { g_hsw_stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    if ((i) == 0) g_hsw_stamps[(size_t)blockIdx.x * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } } while (0)
 #else
 #define HSW_STAMP(i) do { } while (0)
 #endif
