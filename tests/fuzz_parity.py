@@ -93,6 +93,7 @@ class Fuzzer:
                        (0, 1), (0, 8)][int(rng.integers(0, 12))]
         split = int(rng.choice([-1, -1, 0, 1, 2]))
         helpers = int(rng.integers(0, 5))                          # waves per workgroup of the small-batch kernel
+        mont_emit = int(rng.choice([1, 1, 0, 2]))                  # Montgomery cells: converted at emit time (default mode / always) or at write-out
         shift = int(rng.choice([0, 0, 1, 2, 3]))
         pack = rng.random() < 0.4
         chunk = int(rng.choice([1 << 20, 1 << 20, 1, 3, 5]))      # blocks per launch: reach the multi-launch loop
@@ -100,8 +101,9 @@ class Fuzzer:
             internals, bits, ncols, n, cursor0, flags = (override[k] for k in ("internals", "bits", "ncols", "n", "cursor0", "flags"))
             tile, parts, split, shift, pack, chunk = (override[k] for k in ("tile", "parts", "split", "shift", "pack", "chunk"))
             helpers = override.get("helpers", 0)
+            mont_emit = override.get("mont_emit", 1)
         desc = dict(kind="blocks", internals=internals, bits=bits, ncols=ncols, n=n, cursor0=cursor0, flags=flags,
-                    tile=tile, parts=parts, split=split, helpers=helpers, shift=shift, pack=pack, chunk=chunk)
+                    tile=tile, parts=parts, split=split, helpers=helpers, mont_emit=mont_emit, shift=shift, pack=pack, chunk=chunk)
         self.current = desc
         eng = self.engine(bits, ncols, internals)
         G, LK = eng.G, eng.lookup_cells
@@ -162,6 +164,7 @@ class Fuzzer:
         if helpers:
             eng.set_option("helpers", helpers)
         eng.set_option("chunk_blocks", chunk)
+        eng.set_option("mont_emit", mont_emit)
         try:
             rc = eng.lib.hsw_witness_blocks_ex(eng.h, C.byref(a))
             if rc == N.HSW_ERR_UNSUPPORTED:      # e.g. more than two column breaks inside one block
@@ -176,6 +179,7 @@ class Fuzzer:
             if helpers:
                 eng.set_option("helpers", 0)
             eng.set_option("chunk_blocks", 1 << 20)
+            eng.set_option("mont_emit", 1)
         ref = self.O.Oracle(bits, ncols, check=False, internals=internals).witness_blocks(blocks, pre, cursor0=cursor0)
         eg, ed, es, el = self._expected(ref, eng, n, flags, internals)
         flat = big.cpu().numpy().view(np.uint64)
@@ -357,11 +361,24 @@ class Fuzzer:
         batch = bool(rng.integers(0, 2))
         mont = rng.random() < 0.35
         columns = rng.random() < 0.4
+        # hsw_gadget_set_origin: the Context stands at (column, row), may cache its zero cell and have lookups queued
+        origin = None
+        if rng.random() < 0.35:
+            origin = (int(rng.integers(0, 4)), 0, bool(rng.integers(0, 2)), int(rng.choice([0, 0, 1, int(rng.integers(0, 3000))])))
+        # HSW_GADGET_INDEPENDENT: every digest a Context of its own (linear streams, no origin)
+        independent = origin is None and not columns and rng.random() < 0.25
+        distinct = rng.random() < 0.3
         desc = dict(kind="digests", bits=bits, ncols=ncols, sizes=sizes, lens=[len(m) for m in msgs], pres=pres, rc=rc,
-                    batch=batch, mont=mont, columns=columns)
+                    batch=batch, mont=mont, columns=columns, origin=origin, independent=independent, distinct=distinct)
         self.current = desc
         eng = self.engine(bits, ncols, True)
-        cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True)
+        try:
+            cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=rc, whole_digest=True, independent=independent)
+        except hsw.HswError as ex:
+            if independent and ex.status == N.HSW_ERR_UNSUPPORTED:       # a context's chip rows would not start on a row boundary
+                self.stats["skipped"] += 1
+                return desc
+            raise
         max_rows = None
         try:
             if mont:
@@ -369,6 +386,14 @@ class Fuzzer:
             if columns:
                 max_rows = int(rng.integers(eng.G + 16, 4 * eng.G))
                 desc["max_rows"] = max_rows
+            if origin is not None:
+                if columns:
+                    r0 = int(rng.choice([0, 1, max_rows - 1, int(rng.integers(0, max_rows))]))
+                    origin = (origin[0], r0, origin[2], origin[3])
+                    desc["origin"] = origin
+                    self.current = desc
+                cfg.set_origin(*origin)
+            if columns:
                 try:
                     cfg.set_columns(max_rows)
                 except hsw.HswError as ex:
@@ -384,18 +409,50 @@ class Fuzzer:
                 for k in ("gate", "lookup", "dense", "spread"):
                     assert np.array_equal(host[k], st[k]), "download_region %s differs from the device image" % k
                 self.stats["downloads"] = self.stats.get("downloads", 0) + 1
+            if distinct:                              # distinct-value delivery + host replay: the same image again
+                got = cfg.download_region_distinct(threads=int(rng.integers(1, 5)))
+                for k in ("gate", "lookup", "dense", "spread"):
+                    assert np.array_equal(got[k], st[k]), "distinct-value delivery: %s differs from the device image" % k
+                assert 0 < got["n_distinct"] < int(cfg.view().gate_cells)
+                self.stats["distinct"] = self.stats.get("distinct", 0) + 1
         finally:
             cfg.close()
-        if nd >= 2 and rng.random() < 0.25:
-            self._seek_split(eng, sizes, msgs, pres, rc, mont, max_rows if columns else None, st, int(rng.integers(1, nd)))
-        ref = self.O.digest_cells(msgs, sizes, pres, rc, num_bits_lookup=bits, num_advice_columns=ncols)
         for m, r in zip(msgs, res):
             assert r.output_bytes == hashlib.sha256(m).digest(), "digest differs from SHA-256"
         conv = self.O.to_montgomery if mont else (lambda x: x)
+        if independent:
+            # every digest's slice of the streams is what a fresh single-digest gadget writes
+            at_g = at_l = 0
+            lc = int(eng.shape.limb_calls_per_block)
+            for m, mx, pz, r in zip(msgs, sizes, pres, res):
+                one = self.O.digest_cells([m], [mx], [pz], rc, num_bits_lookup=bits, num_advice_columns=ncols)
+                ng, nl = len(one["gate"]), len(one["lookup"])
+                assert r.prologue_cell == at_g and r.end_cell == at_g + ng, "independent context: positions differ"
+                assert np.array_equal(st["gate"][at_g: at_g + ng], conv(one["gate"])), "independent context: gate slice differs"
+                assert np.array_equal(st["lookup"][at_l: at_l + nl], conv(one["lookup"])), "independent context: lookup slice differs"
+                row0 = r.first_block * lc // ncols    # (a context's chip rows start on a row of their own, or the gadget is refused)
+                for k in ("dense", "spread"):
+                    c1 = conv(one[k])
+                    assert np.array_equal(st[k][:, row0: row0 + c1.shape[1]], c1), "independent context: chip %s rows differ" % k
+                at_g, at_l = at_g + ng, at_l + nl
+            assert at_g == len(st["gate"]) and rep["violations"] == 0, rep
+            self.stats["independent"] = self.stats.get("independent", 0) + 1
+            self.stats["digest_runs"] += 1
+            self.stats["digest_cells"] += at_g
+            return desc
+        if nd >= 2 and origin is None and rng.random() < 0.25:
+            self._seek_split(eng, sizes, msgs, pres, rc, mont, max_rows if columns else None, st, int(rng.integers(1, nd)))
+        zero = bool(origin[2]) if origin is not None else False
+        lq = origin[3] if origin is not None else 0
+        ref = self.O.digest_cells(msgs, sizes, pres, rc, num_bits_lookup=bits, num_advice_columns=ncols, zero_cell_loaded=zero)
+        assert not st["lookup"][:lq].any(), "lookup entries queued by the caller were written"
+        st = dict(st, lookup=st["lookup"][lq:])
+        if origin is not None:
+            self.stats["origins"] = self.stats.get("origins", 0) + 1
         if columns:
             # halo2-lib v0.2.x FlexGate::assign_region over the oracle's call tape (assumption A3-iii)
             g = conv(ref["gate"])
-            cols, col, row, at = [np.zeros((max_rows, 4), dtype=np.uint64)], 0, 0, 0
+            cols, col, row, at = [np.zeros((max_rows, 4), dtype=np.uint64)], 0, (origin[1] if origin is not None else 0), 0
             for ln in ref["call_lens"].tolist():
                 if row + ln >= max_rows:
                     cols.append(np.zeros((max_rows, 4), dtype=np.uint64))
