@@ -822,7 +822,7 @@ int hsw_gadget_set_columns(hsw_gadget *g, uint64_t max_rows, uint64_t *n_columns
     int rc = hsw_engine_synchronize(g->ctx->engine);          // the image is reallocated: nothing may still write the old one
     if (rc == HSW_OK) rc = g->ctx->set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, max_rows);
     if (rc == HSW_OK && n_columns) *n_columns = g->ctx->columns;
-    if (rc == HSW_OK) { hsw::free_region_tape(g->tape); g->tape = nullptr; }     // positions follow the layout
+    if (rc == HSW_OK) hsw::drop_region_tape_positions(g->tape);     // the codes are per stream cell; image positions follow the layout
     return rc;
 } HSW_NO_UNWIND
 
@@ -836,8 +836,11 @@ int hsw_gadget_set_origin(hsw_gadget *g, uint64_t column, uint64_t row, int zero
     const uint64_t old[4] = {c.origin_column, c.origin_row, c.origin_zero_loaded ? 1u : 0u, c.origin_lookups};
     rc = c.set_origin(column, row, zero_cell_loaded != 0, lookups_already_queued);
     if (rc != HSW_OK) return rc;
-    hsw::free_region_tape(g->tape);                        // zero cell and positions follow the origin
-    g->tape = nullptr;
+    // the region tape (hsw_replay.cpp) numbers stream cells: only a zero cell that comes or goes changes it; a new
+    // origin row moves the witnesses' image positions; column and queued lookups are offsets applied at delivery.
+    // A prover that synthesizes the same circuit pass after pass keeps its tape.
+    if (old[2] != (zero_cell_loaded ? 1u : 0u)) { hsw::free_region_tape(g->tape); g->tape = nullptr; }
+    else if (old[1] != row) hsw::drop_region_tape_positions(g->tape);
     if (c.max_rows && (old[1] != row || old[2] != (zero_cell_loaded ? 1u : 0u))) {
         // the column breaks follow from where the stream starts: lay the image out again
         rc = c.set_columns(g->cfg.max_variable_byte_sizes, g->cfg.is_input_range_check, c.max_rows);

@@ -160,6 +160,7 @@ class Context {
 // cell of the gate / lookup / chip streams which witness or constant it repeats.
 struct RegionTape;
 void free_region_tape(RegionTape *t);
+void drop_region_tape_positions(RegionTape *t);
 
 }  // namespace hsw
 

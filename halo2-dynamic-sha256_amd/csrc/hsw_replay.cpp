@@ -56,6 +56,20 @@ void free_region_tape(RegionTape *t) {
     delete t;
 }
 
+// The layout moved (column height, origin row) but the stream did not: the codes stay, the image positions of
+// the witnesses are worked out again at the next delivery.
+void drop_region_tape_positions(RegionTape *t) {
+    if (!t || (!t->d_wit_pos && !t->d_distinct)) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != t->device) (void)hipSetDevice(t->device);
+    (void)hipFree(t->d_wit_pos);
+    (void)hipFree(t->d_distinct);
+    t->d_wit_pos = nullptr;
+    t->d_distinct = nullptr;
+    if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+}
+
 namespace {
 
 constexpr uint32_t TAPE_CONST = 0x80000000u;

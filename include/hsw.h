@@ -627,8 +627,9 @@ int hsw_region_widen(const uint64_t *compact, size_t n_cells, uint64_t stream_id
  *                                       "never touch the caller's cells" rules as there -- from the distinct
  *                                       values, with `threads` host threads (pure host work; a consumer that
  *                                       walks the region cell by cell anyway can read value(code[i]) itself)
- * The tape pointers stay valid until the layout changes (hsw_gadget_set_columns / _set_origin) or the gadget
- * is destroyed.  HSW_ERR_TOO_LARGE: cap_cells too small (*n_cells says how many), or a region of 2^30 cells or more. */
+ * The tape numbers STREAM cells, so it survives hsw_gadget_reset, a new column height and a new origin column /
+ * row / lookup count (a prover that synthesizes one circuit pass after pass builds it once); its pointers stay
+ * valid until hsw_gadget_set_origin is given a different zero_cell_loaded or the gadget is destroyed.  HSW_ERR_TOO_LARGE: cap_cells too small (*n_cells says how many), or a region of 2^30 cells or more. */
 #define HSW_TAPE_CONST 0x80000000u
 typedef struct hsw_region_tape {
     uint64_t n_distinct;                 /* distinct values of the digests assigned so far in this pass */

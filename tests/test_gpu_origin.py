@@ -282,3 +282,45 @@ def test_distinct_value_delivery_rebuilds_the_region(hsw, oracle, eng_int, layou
     else:
         assert np.array_equal(st["gate"], vals)
     cfg.close()
+
+
+def test_the_tape_survives_synthesis_passes(hsw, oracle, eng_int):
+    """A prover synthesizes the same circuit pass after pass: reset + set_origin at the same place must not cost a
+    new tape (1.1 M cells walked on the host for the bench circuit).  The codes number STREAM cells: a new origin
+    row or column height only moves the witnesses' image positions; only a zero cell that comes or goes changes
+    the stream itself.  Every delivery stays bit-equal to hsw_gadget_download_region."""
+    N = hsw._native
+    sizes, msgs = [128, 128], [b"abc", b""]
+    cfg = hsw.Sha256DynamicConfig(eng_int, sizes, is_input_range_check=True, whole_digest=True)
+    cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    cfg.set_origin(1, 500, False, 3)
+    cfg.set_columns(MAX_ROWS)
+
+    def one_pass(origin):
+        cfg.reset()
+        cfg.set_origin(*origin)
+        cfg.digest_batch(msgs)
+        tape = N.RegionTape()
+        cfg._ok(cfg.lib.hsw_gadget_region_tape(cfg.h, C.byref(tape)))
+        full = cfg.download_region(pinned=False)
+        got = cfg.download_region_distinct(threads=2)
+        lq = origin[3]
+        assert np.array_equal(got["gate"], full["gate"]) and np.array_equal(got["lookup"][lq:], full["lookup"][lq:])
+        assert np.array_equal(got["dense"], full["dense"]) and np.array_equal(got["spread"], full["spread"])
+        return C.cast(tape.gate_code, C.c_void_p).value, (int(tape.distinct_capacity), int(tape.gate_cells))
+
+    p0, n0 = one_pass((1, 500, False, 3))
+    p1, n1 = one_pass((1, 500, False, 3))                   # the usual case: the same place again
+    assert (p1, n1) == (p0, n0)
+    p2, n2 = one_pass((4, 500, False, 77))                  # another column, more lookups queued: offsets only
+    assert (p2, n2) == (p0, n0)
+    p3, n3 = one_pass((0, 130990, False, 0))                # another row: the breaks move, the stream does not
+    assert (p3, n3) == (p0, n0)
+    cfg.reset()
+    cfg.set_origin(0, 130, False, 0)                        # (row 130,990 does not exist in the shorter columns)
+    cfg.set_columns(MAX_ROWS - 1000)                         # between passes: another column height
+    p4, n4 = one_pass((0, 130, False, 0))
+    assert (p4, n4) == (p0, n0)
+    p5, n5 = one_pass((0, 130, True, 0))                    # the Context now caches its zero cell: the stream is one
+    assert n5 == (n0[0], n0[1] - 1)                         # cell shorter (a constant: as many distinct values), new tape
+    cfg.close()
