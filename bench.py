@@ -554,7 +554,9 @@ def extra_config0(hsw, local_rank, with_cpu):
         # input-independent tape rebuilds copies and constants on the host (hsw_replay.cpp)
         try:
             tape = hsw._native.RegionTape()
-            assert L.hsw_gadget_region_tape(cfgm.h, C.byref(tape)) == 0
+            t1 = time.perf_counter()
+            assert L.hsw_gadget_region_tape(cfgm.h, C.byref(tape)) == 0      # first call: builds the tape (once per circuit)
+            tape_build_ms = (time.perf_counter() - t1) * 1e3
             himg = cfgm.download_region(pinned=True)                 # the 32-byte delivery, as the reference image
             dbuf = eng_i.host_empty((int(tape.distinct_capacity), 4))
             rgate, rlook = eng_i.host_empty(himg["gate"].shape), eng_i.host_empty(himg["lookup"].shape)
@@ -584,6 +586,7 @@ def extra_config0(hsw, local_rank, with_cpu):
                 "full_32_byte_cells_ms": float(np.median(t_full)) * 1e3, "full_bytes": (int(vw.gate_cells) + int(vw.lookup_cells)) * 32,
                 "distinct_ms": float(np.median(t_dist)) * 1e3, "distinct_cells": int(nd.value), "distinct_bytes": int(nd.value) * 32,
                 "replay_ms": float(np.median(t_rep)) * 1e3, "replay_threads": threads,
+                "tape_build_ms_once_per_circuit": tape_build_ms,
                 "distinct_plus_replay_ms": float(np.median(np.array(t_dist) + np.array(t_rep))) * 1e3,
                 "note": "synthesis + hsw_gadget_download_region_distinct (the new witnesses only, Montgomery form, pinned memory); "
                         "hsw_gadget_replay_region rebuilds gate image + lookup column on the host (checked bit-equal to the "

@@ -475,8 +475,10 @@ int hsw_witness_blocks_impl(hsw_engine *e, const hsw_witness_args *args, const h
         // finished 32-byte cells, one wave per block (hsw_expand.hpp Em::M32)
         // (default mode only unless forced: with the internals-mode tile -- realignment columns, lookup staging -- it
         //  drops to 4 waves per CU and loses to the write-out conversion, 2.35 vs 1.96 ms)
+        // (and only for launches that fill the chip with one wave per block: below ~1,500 blocks the write-out
+        //  conversion, which spreads a block over up to 16 waves, is faster -- 160 blocks 0.15 against 0.30 ms)
         const bool m32 = !small && e->limbs == 2 && (flags & HSW_REPR_MONTGOMERY) && !(p.flags & hsw::HSW_K_SPLIT) &&
-                         (e->mont_emit == 2 || (e->mont_emit == 1 && e->mode != HSW_MODE_HALO2_INTERNALS));
+                         (e->mont_emit == 2 || (e->mont_emit == 1 && e->mode != HSW_MODE_HALO2_INTERNALS && n >= 1536));
         if (m32) {
             const int rc = ensure_mont_tab(e);
             if (rc != HSW_OK) return rc;

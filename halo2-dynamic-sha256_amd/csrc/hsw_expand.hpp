@@ -134,43 +134,46 @@ DEV Fe8 mont_from_u64(u32 lo, u32 hi) {
                        0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     const u32 R32[8] = {0x15b8b9dau, 0x93e78865u, 0xb05ea154u, 0x16df2426u,      // 2^288 mod p
                         0x302ab839u, 0x1271b743u, 0xec6c226eu, 0x06bc037eu};
+    // Every product below is a 32 x 32 + 64-bit multiply-add (v_mad_u64_u32), the carry travelling in the high
+    // word of the accumulator: (2^32 - 1)^2 + 2^32 - 1 < 2^64, so a chain never overflows.
     u32 t[9];
-    u32 cy;
-    {   // t = lo * R: low halves at limb j, high halves at limb j + 1
-        u32 h[8];
+    {   // t = lo * R
+        u64 acc = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { t[j] = lo * RR[j]; h[j] = __umulhi(lo, RR[j]); }
-        cy = 0;
-#pragma unroll
-        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h[j - 1], cy, &cy);
-        t[8] = h[7] + cy;
+        for (int j = 0; j < 8; j++) { acc = (u64)lo * RR[j] + (acc >> 32); t[j] = (u32)acc; }
+        t[8] = (u32)(acc >> 32);
     }
-    if (HAS_HI) {   // t += hi * R32
-        u32 l2[8], h2[8];
+    if (HAS_HI) {   // t += hi * R32   (t < 2^33 p < 2^288 afterwards: nine limbs hold it)
+        u32 u[9];
+        u64 acc = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { l2[j] = hi * R32[j]; h2[j] = __umulhi(hi, R32[j]); }
-        cy = 0;
+        for (int j = 0; j < 8; j++) { acc = (u64)hi * R32[j] + (acc >> 32); u[j] = (u32)acc; }
+        u[8] = (u32)(acc >> 32);
+        u32 cy = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) t[j] = __builtin_addc(t[j], l2[j], cy, &cy);
-        t[8] += cy;
-        cy = 0;
-#pragma unroll
-        for (int j = 1; j < 8; j++) t[j] = __builtin_addc(t[j], h2[j - 1], cy, &cy);
-        t[8] += h2[7] + cy;
+        for (int j = 0; j < 8; j++) t[j] = __builtin_addc(t[j], u[j], cy, &cy);
+        t[8] += u[8] + cy;
     }
-    const u64 th = ((u64)t[8] << 32) | t[7];
-    const u32 q = (u32)__umul64hi(th, HSW_MU);            // < 0.43 * 2^32
+    // q = floor((t >> 224) * floor(2^288 / p) / 2^64), the multiplier being 5 * 2^32 + MU0      (q < 0.43 * 2^32)
+    constexpr u32 MU0 = (u32)HSW_MU;
+    static_assert((HSW_MU >> 32) == 5ull, "Barrett multiplier");
+    u64 mid = (u64)t[7] * MU0;
+    mid = (u64)t[8] * MU0 + (mid >> 32);
+    mid = (u64)t[7] * 5u + mid;
+    u32 q = t[8] * 5u + (u32)(mid >> 32);
+    asm("" : "+v"(q));      // a 32-bit value from here on (otherwise the sum is widened and q * p becomes 64 x 256 bits)
     // r = (t - q*p) mod 2^256 (the true value is < 2p < 2^256)
-    u32 ql[8], qh[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { ql[j] = q * P[j]; qh[j] = __umulhi(q, P[j]); }
     Fe8 r;
-    u32 br = 0;
+    {
+        u64 acc = 0;
+        u32 br = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = __builtin_subc(t[j], ql[j], br, &br);
-    br = 0;
-#pragma unroll
-    for (int j = 1; j < 8; j++) r.l[j] = __builtin_subc(r.l[j], qh[j - 1], br, &br);
+        for (int j = 0; j < 8; j++) {
+            acc = (u64)q * P[j] + (acc >> 32);
+            r.l[j] = __builtin_subc(t[j], (u32)acc, br, &br);
+        }
+    }
+    u32 br;
     u32 sub[8];
     br = 0;
 #pragma unroll

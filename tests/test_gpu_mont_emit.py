@@ -1,7 +1,8 @@
 """Montgomery cells converted at EMIT time (hsw_expand.hpp Em::M32: tiles of finished 32-byte cells, every
 distinct value of a unit converted once, byte tables for the limbs and 16-bit witnesses) against the oracle and
 against the write-out conversion (one multiply + Barrett step per cell) -- same bytes either way.  The engine
-uses it for streaming launches in default mode; "mont_emit" = 2 forces it in internals mode too, which is what
+uses it for streaming launches of 1,536 blocks or more in default mode (one wave per block: smaller launches
+would not fill the chip); "mont_emit" = 2 forces it for any size and in internals mode too, which is what
 exercises its realigning write-out, column breaks and the lookup column."""
 import numpy as np
 import pytest
@@ -27,7 +28,7 @@ def test_emit_time_conversion_default_mode(hsw, oracle, n, cursor0, ncols):
     ref = oracle.Oracle(8, ncols, check=False).witness_blocks(blocks, pre, cursor0=cursor0)
     tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
     outs = []
-    for emit in (1, 0):
+    for emit in (2, 0):
         eng = hsw.WitnessEngine(0, 8, ncols)
         eng.set_option("split", 0)                  # the streaming kernel also for the 3-block batch
         eng.set_option("mont_emit", emit)
@@ -76,3 +77,27 @@ def test_emit_time_conversion_internals_mode(hsw, oracle, n, start_row, max_rows
     assert (flat == np.uint64(2**64 - 1)).all(axis=1).sum() == flat.shape[0] - ref["gate"].shape[0]   # only the gaps are untouched
     used = ~(flat == np.uint64(2**64 - 1)).all(axis=1)
     assert np.array_equal(flat[used], oracle.to_montgomery(ref["gate"]))
+
+
+def test_default_engages_emit_time_conversion_from_1536_blocks(hsw):
+    """Default options: launches of 1,536 blocks or more take the emit-time kernel, smaller ones the write-out
+    conversion (which spreads a block over up to 16 waves); both give the same bytes."""
+    import torch
+    N = hsw._native
+    blocks, pre = _inputs(1536, 99)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    eng = hsw.WitnessEngine(0, 8, 2)
+    out = eng.witness_blocks(tb, tp, flags=N.HSW_REPR_MONTGOMERY)
+    eng.synchronize()
+    assert eng.last_launch()["repr"] == 3
+    big = {k: out[k].clone() for k in ("gate", "dense", "spread", "next_states")}
+    del out
+    small = eng.witness_blocks(tb[:1535], tp[:1535], flags=N.HSW_REPR_MONTGOMERY)
+    eng.synchronize()
+    assert eng.last_launch()["repr"] == 1
+    G = eng.G
+    assert torch.equal(small["gate"].view(-1, 4)[: 1535 * G], big["gate"].view(-1, 4)[: 1535 * G])
+    assert torch.equal(small["next_states"], big["next_states"][:1535])
+    rows = small["dense"].shape[1] - 1               # (the last chip row of the shorter batch may be partial)
+    assert torch.equal(small["dense"][:, :rows], big["dense"][:, :rows]) and torch.equal(small["spread"][:, :rows], big["spread"][:, :rows])
+    eng.close()
