@@ -43,6 +43,31 @@ def run():
     print("block streams: median %.1f us, min %.1f us" % (ts[len(ts) // 2] * 1e6, ts[0] * 1e6))
 
 
+def run_k(k, mont):
+    """K independent syntheses of the bench circuit in one hsw_gadget_digest_batch call (bench.py's `batched`)."""
+    import numpy as np
+    hsw = importlib.import_module("halo2-dynamic-sha256_amd")
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+    cfg = hsw.Sha256DynamicConfig(eng, [1024] * k, True, whole_digest=True, independent=True)
+    if mont:
+        cfg.set_repr(N.HSW_REPR_MONTGOMERY)
+    rng = np.random.default_rng(5)
+    msgs = [rng.integers(0, 256, 56, dtype=np.uint8).tobytes() for _ in range(k)]
+    for _ in range(3):
+        cfg.reset(); cfg.digest_batch(msgs)
+    ts = []
+    for _ in range(8):
+        cfg.reset()
+        t = time.perf_counter()
+        cfg.digest_batch(msgs)
+        ts.append(time.perf_counter() - t)
+        time.sleep(0.005)
+    ts.sort()
+    print("K = %d %s: median %.1f us, min %.1f us" % (k, "montgomery" if mont else "canonical", ts[len(ts) // 2] * 1e6, ts[0] * 1e6))
+    cfg.close()
+
+
 def summarise(db):
     cur = sqlite3.connect(db).cursor()
     ev = [(s, e, "K " + n.split("(")[0][-60:]) for n, s, e in cur.execute("select name, start, end from kernels")]
@@ -59,7 +84,7 @@ def summarise(db):
         cur_g.append((s, e, n))
     if cur_g:
         groups.append(cur_g)
-    for g in groups[-45:-38] + groups[-3:]:
+    for g in (groups[-3:] if len(groups) < 60 else groups[-45:-38] + groups[-3:]):
         t0 = g[0][0]
         print("--- %d events, span %.1f us" % (len(g), (g[-1][1] - t0) / 1e3))
         for s, e, n in g:
@@ -69,5 +94,7 @@ def summarise(db):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "runk":
+        run_k(int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "montgomery")
     else:
         summarise(sys.argv[2])
