@@ -140,6 +140,16 @@ static void whole_region() {
     CHECK(hsw_gadget_set_columns(g, 200000, &columns) == HSW_OK && columns == 2);
     digest_both();
     deliver();
+    // pass 4: the same stream from another row and column: the tape is kept, only the witnesses' image positions
+    // are worked out again (hsw_replay.cpp drop_region_tape_positions)
+    hsw_region_tape before, after;
+    CHECK(hsw_gadget_region_tape(g, &before) == HSW_OK);
+    CHECK(hsw_gadget_reset(g) == HSW_OK);
+    CHECK(hsw_gadget_set_origin(g, 1, 500, 0, 5) == HSW_OK);
+    digest_both();
+    deliver();
+    CHECK(hsw_gadget_region_tape(g, &after) == HSW_OK);
+    CHECK(after.gate_code == before.gate_code && after.distinct_capacity == before.distinct_capacity);
     CHECK(hsw_gadget_seek(g, 1) == HSW_OK);
     CHECK(hsw_gadget_digest(g, nullptr, 0, 0, &r[1]) == HSW_OK);
     hsw_gadget_destroy(g);
