@@ -22,6 +22,14 @@ static void read_cell(hsw_engine *eng, const hsw_gadget_view *v, const uint64_t 
     if (rc != HSW_OK) die("hsw_download", rc, eng);
 }
 
+/* The same cell the way the Rust shim takes it (rust/reference-patch/src/hsw.rs): only the region's DISTINCT values
+ * cross PCIe, the input-independent tape says which of them -- or which gate constant -- stream cell i holds. */
+static void tape_cell(const hsw_region_tape *t, const uint64_t (*distinct)[4], uint64_t stream_cell, uint64_t out[4]) {
+    const uint32_t code = t->gate_code[stream_cell];
+    const uint64_t *src = (code & HSW_TAPE_CONST) ? ((const uint64_t (*)[4])t->consts)[code & ~HSW_TAPE_CONST] : distinct[code];
+    memcpy(out, src, 32);
+}
+
 /* origin: where the circuit's Context stands when it calls digest() for the first time -- (0, 0, fresh) for the
  * reference's own circuits, anything for a circuit that has used the gate / range chips before */
 typedef struct { uint64_t column, row, lookups_queued; int zero_cell_loaded; } origin_t;
@@ -51,13 +59,24 @@ static int check_circuit(const char *name, const size_t *sizes, size_t n, const 
     uint64_t c0 = 0, r0 = 0;
     if ((rc = hsw_gadget_cell_position(g, 0, &c0, &r0)) != HSW_OK) die("cell_position", rc, eng);
     if (o.row + 1 < v.max_rows && (c0 != o.column || r0 != o.row)) { fprintf(stderr, "%s: origin\n", name); return 1; }
+    /* distinct-value delivery: tape (built once per circuit) + the new witnesses in pinned memory */
+    hsw_region_tape tape;
+    if ((rc = hsw_gadget_region_tape(g, &tape)) != HSW_OK) die("hsw_gadget_region_tape", rc, eng);
+    void *dist_mem = NULL;
+    if ((rc = hsw_host_alloc(tape.distinct_capacity * HSW_CELL_BYTES, &dist_mem)) != HSW_OK) die("hsw_host_alloc", rc, eng);
+    const uint64_t (*distinct)[4] = (const uint64_t (*)[4])dist_mem;
+    size_t n_distinct = 0;
+    if ((rc = hsw_gadget_download_region_distinct(g, dist_mem, tape.distinct_capacity, &n_distinct)) != HSW_OK) die("download_region_distinct", rc, eng);
+    if (tape.gate_cells != v.gate_cells || n_distinct != tape.n_distinct || 2 * n_distinct > tape.gate_cells) return 1;
     for (size_t i = 0; i < n; i++) {
         hsw_result_cells rc_;
         if ((rc = hsw_gadget_result_cells(g, i, &rc_)) != HSW_OK) die("hsw_gadget_result_cells", rc, eng);
-        uint64_t cell[4];
+        uint64_t cell[4], via_tape[4];
         /* input_len (lib.rs:124-125) */
         read_cell(eng, &v, rc_.input_len_pos, cell);
         if (cell[0] != lens[i] || cell[1] || cell[2] || cell[3]) { fprintf(stderr, "%s: input_len cell\n", name); return 1; }
+        tape_cell(&tape, distinct, rc_.input_len_cell, via_tape);
+        if (memcmp(cell, via_tape, 32) != 0) { fprintf(stderr, "%s: input_len through the tape\n", name); return 1; }
         /* input_bytes (lib.rs:170-173): the padded message, max_variable_byte_size cells */
         if (rc_.n_input_bytes != sizes[i]) return 1;
         uint8_t *padded = calloc(sizes[i], 1);
@@ -70,6 +89,8 @@ static int check_circuit(const char *name, const size_t *sizes, size_t n, const 
             if (b == 0 && (pos[0] != rc_.input_bytes_pos0[0] || pos[1] != rc_.input_bytes_pos0[1])) return 1;
             read_cell(eng, &v, pos, cell);
             if (cell[0] != padded[b] || cell[1] || cell[2] || cell[3]) { fprintf(stderr, "%s: input byte %zu\n", name, b); return 1; }
+            tape_cell(&tape, distinct, rc_.input_bytes_cell0 + b, via_tape);
+            if (memcmp(cell, via_tape, 32) != 0) { fprintf(stderr, "%s: input byte %zu through the tape\n", name, b); return 1; }
         }
         free(padded);
         /* output_bytes (lib.rs:317-324): what constrain_instance ties to the instance column */
@@ -77,6 +98,8 @@ static int check_circuit(const char *name, const size_t *sizes, size_t n, const 
         for (int k = 0; k < 32; k++) {
             read_cell(eng, &v, rc_.output_byte_pos[k], cell);
             if (cell[0] != r[i].output_bytes[k] || cell[1] || cell[2] || cell[3]) { fprintf(stderr, "%s: output byte %d\n", name, k); return 1; }
+            tape_cell(&tape, distinct, rc_.output_byte_cells[k], via_tape);
+            if (memcmp(cell, via_tape, 32) != 0) { fprintf(stderr, "%s: output byte %d through the tape\n", name, k); return 1; }
             sprintf(hex + 2 * k, "%02x", (unsigned)cell[0]);
         }
         printf("%s digest %zu: input_len at (%llu, %llu), input_bytes from (%llu, %llu), output_bytes[0] at (%llu, %llu): %s\n", name, i,
@@ -84,6 +107,7 @@ static int check_circuit(const char *name, const size_t *sizes, size_t n, const 
                (unsigned long long)rc_.input_bytes_pos0[0], (unsigned long long)rc_.input_bytes_pos0[1],
                (unsigned long long)rc_.output_byte_pos[0][0], (unsigned long long)rc_.output_byte_pos[0][1], hex);
     }
+    hsw_host_free(dist_mem);
     hsw_gadget_destroy(g);
     hsw_engine_destroy(eng);
     return 0;

@@ -102,9 +102,7 @@ struct Backend {
     // where the Context must stand for the gadget's NEXT digest of this pass: (advice_alloc[0], cells_to_lookup.len())
     // as the previous digest left them; None = the pass is not (or no longer) on the GPU
     expect: Option<((usize, usize), usize)>,
-    max_rows: u64,
     chip_columns: usize,
-    chip_col_stride: usize,
     // pinned host buffer (hsw_host_alloc) for the region's DISTINCT values: ~40 % of its cells -- the rest repeat
     // one of them or hold a gate constant, at input-independent positions the tape names (hsw.h, distinct-value
     // delivery: 0.33 ms instead of 0.81 ms for the bench circuit's region)
@@ -118,8 +116,8 @@ impl Backend {
     fn new<F: PrimeField>(sha256: &Sha256DynamicConfig<F>, key: (Vec<usize>, usize, usize, bool, u64)) -> Result<Self, Error> {
         let device = std::env::var("HSW_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         // `be` owns whatever exists so far: an early `?` drops it and Drop releases engine / gadget / staging
-        let mut be = Self { engine: ptr::null_mut(), gadget: ptr::null_mut(), key, expect: None, max_rows: 0,
-                            chip_columns: sha256.spread_config.num_advice_columns, chip_col_stride: 0,
+        let mut be = Self { engine: ptr::null_mut(), gadget: ptr::null_mut(), key, expect: None,
+                            chip_columns: sha256.spread_config.num_advice_columns,
                             distinct: ptr::null_mut(), distinct_cells: 0 };
         check(unsafe { sys::hsw_engine_create_ex(device, ptr::null_mut(), be.key.1 as u32, be.key.2 as u32,
                                                  sys::HSW_MODE_HALO2_INTERNALS, &mut be.engine) })?;
@@ -130,10 +128,6 @@ impl Backend {
         // the column image from (0, 0); every synthesis pass re-bases it on where its Context stands (set_origin)
         let mut columns = 0u64;
         check(unsafe { sys::hsw_gadget_set_columns(be.gadget, be.key.4, &mut columns) })?;
-        let mut view = unsafe { std::mem::zeroed::<sys::hsw_gadget_view>() };
-        check(unsafe { sys::hsw_gadget_streams(be.gadget, &mut view) })?;
-        be.max_rows = view.max_rows;
-        be.chip_col_stride = view.chip_col_stride;
         let mut tape = unsafe { std::mem::zeroed::<sys::hsw_region_tape>() };
         check(unsafe { sys::hsw_gadget_region_tape(be.gadget, &mut tape) })?;
         be.distinct_cells = tape.distinct_capacity as usize + 1;             // every digest of the circuit
@@ -180,8 +174,7 @@ pub fn digest_gpu<'a, 'b: 'a, F: PrimeField>(sha256: &'a mut Sha256DynamicConfig
         };
         // ---- phase 2: hand the cells to halo2.  Errors here are halo2's own and propagate.
         let Fetched { r, rc, view, segs, end, tape } = fetched;
-        let (ocol, c) = (view.origin_column, be.chip_columns as u64);
-        let _ = ocol;
+        let c = be.chip_columns as u64;
         let gate_cols: Vec<Column<Advice>> = sha256.range().gate.basic_gates[0].iter().map(|g| g.value).collect();
         // cell i of a stream holds value(code[i]): a gate constant or one of the distinct values fetch() brought over
         let (distinct, consts) = (be.distinct as *const [u64; 4], tape.consts as *const [u64; 4]);
