@@ -706,6 +706,9 @@ int hsw_fill_calibrate(hsw_engine *e, void *d_buf, size_t bytes, float *ms);
  * 2 = the small-batch kernel always.  "helpers": waves per workgroup (= role) of the small-batch kernel --
  * they share the write-out of every tile; 0 = chosen by the engine (default: 4 for Montgomery cells, else 4 / 2 / 1
  * up to 16 / 64 / 128 blocks), 1..4.  "verify_slices": workgroups per block of hsw_verify_blocks, 0 = default.
+ * "mont_emit": where Montgomery cells of the streaming kernel are converted (8-bit table only) -- 0 = at
+ * write-out always, 1 = at emit time for default-mode launches of 1,536 blocks or more (default; fewer VALU
+ * instructions than the canonical kernel, but one wave per block), 2 = at emit time always (also internals mode).
  * "chunk_blocks": blocks per kernel launch of a long batch (default and maximum 2^20; a test knob). */
 int hsw_engine_set_option(hsw_engine *e, const char *name, int64_t value);
 
