@@ -89,6 +89,45 @@ class WitnessEngine:
         nxt = t.empty((n_blocks, 8), dtype=t.int32, device=self.device)
         return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, rows=rows)
 
+    def alloc_outputs_placed(self, blocks, pre_states, cursor0=0, flags=0, candidates=6, spacer_bytes=6 << 30):
+        """alloc_outputs with a measured choice of WHERE the chip columns sit relative to the gate stream.
+
+        On MI355X the same launch takes 1.64 or 1.77 ms per 4,096 blocks depending on the PAIR of allocations its
+        gate stream and its chip columns live in (profiles/r03_placement_probe.log: the pure fill of either buffer
+        and the launch without chip columns do not care; two regions of ONE allocation are always the slow case).
+        Nothing in user space says which pairs are fast, so a caller that allocates its witness buffers once and
+        reuses them -- a prover does -- times the launch itself on a few candidates and keeps the best:
+        `candidates` (dense, spread) allocations, spaced out by throw-away allocations of `spacer_bytes`.
+        Returns (outputs, report)."""
+        t = self.torch
+        n = blocks.numel() // 64
+        out = self.alloc_outputs(n, cursor0, flags)
+        timing_was = getattr(self, "_timing", False)
+        self.set_timing(True)
+
+        def time_pair(dense, spread):
+            o = dict(out, dense=dense, spread=spread)
+            ms = []
+            for _ in range(4):
+                self.witness_blocks(blocks, pre_states, cursor0=cursor0, out=o, flags=flags)
+                ms.append(self.last_kernel_ms())
+            return float(min(ms[1:]))
+
+        pairs, spacers, times = [(out["dense"], out["spread"])], [], []
+        times.append(time_pair(*pairs[0]))
+        for _ in range(max(candidates - 1, 0)):
+            try:
+                spacers.append(t.empty((spacer_bytes,), dtype=t.uint8, device=self.device))
+                pairs.append((t.zeros_like(out["dense"]), t.zeros_like(out["spread"])))
+            except RuntimeError:          # out of memory: keep what we have
+                break
+            times.append(time_pair(*pairs[-1]))
+        best = int(min(range(len(times)), key=lambda k: times[k]))
+        out["dense"], out["spread"] = pairs[best]
+        del pairs, spacers
+        self.set_timing(timing_was)
+        return out, dict(candidates=len(times), kernel_ms_each=times, kept=best)
+
     # ---- the hot path ----------------------------------------------------
     def witness_blocks(self, blocks, pre_states, cursor0=0, out=None, flags=0):
         """blocks: cuda uint8 (n,64); pre_states: cuda int32 (n,8).  Asynchronous
@@ -225,6 +264,7 @@ class WitnessEngine:
 
     def set_timing(self, on=True):
         self._ok(self.lib.hsw_set_timing(self.h, 1 if on else 0))
+        self._timing = bool(on)
 
     def last_kernel_ms(self):
         ms = C.c_float()
