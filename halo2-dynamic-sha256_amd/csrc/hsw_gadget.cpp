@@ -4,7 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdlib>
+#include <vector>
 #include <cstring>
 #include <new>
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -866,6 +868,78 @@ int hsw_gadget_reset(hsw_gadget *g) try {
     g->cfg.cur_hash_idx = 0;            // lib.rs:66
     g->results.clear();
     return HSW_OK;
+} HSW_NO_UNWIND
+
+// Which allocations the chip columns live in, relative to the gate stream, is worth up to 8 % of an HBM-bound
+// batch on MI355X and nothing in user space predicts it: try `candidates` allocations, timing the
+// gadget's own batch (every digest an empty message) on each, and keep the fastest.
+int hsw_gadget_place(hsw_gadget *g, unsigned candidates, float *ms_each, unsigned *kept) try {
+    if (!g || candidates == 0 || candidates > 16) return HSW_ERR_INVALID_ARG;
+    hsw::Context &c = *g->ctx;
+    if (g->cfg.cur_hash_idx != 0 || c.blocks_done != 0) return HSW_ERR_INVALID_ARG;      // a fresh or reset gadget
+    const size_t n = g->cfg.max_variable_byte_sizes.size();
+    if (n == 0) return HSW_ERR_INVALID_ARG;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    hsw_engine_stream(c.engine, reinterpret_cast<void **>(&stream), &device);
+    hsw::DeviceScopeG ds(device);
+    if (!ds.ok) return HSW_ERR_NO_DEVICE;
+    hsw_shape s;
+    int rc = hsw_engine_shape(c.engine, &s);
+    if (rc != HSW_OK) return rc;
+    const size_t col_bytes = (size_t)s.num_advice_columns * (c.chip_col_stride ? c.chip_col_stride : 1) * HSW_CELL_BYTES;
+    const uint8_t nothing = 0;
+    std::vector<const uint8_t *> in(n, &nothing);
+    std::vector<size_t> lens(n, 0), pres(n, 0);
+    std::vector<hsw_hash_result> res(n);
+    struct Cand { void *dense, *spread; float ms; };
+    std::vector<Cand> cands;
+    auto restore = [&](size_t keep) {                        // install candidate `keep`, free the others
+        for (size_t k = 0; k < cands.size(); k++)
+            if (k != keep) { (void)hipFree(cands[k].dense); (void)hipFree(cands[k].spread); }
+        c.d_chip_dense = cands[keep].dense;
+        c.d_chip_spread = cands[keep].spread;
+    };
+    for (unsigned k = 0; k < candidates; k++) {
+        Cand cd{c.d_chip_dense, c.d_chip_spread, 0.f};
+        if (k > 0) {
+            cd.dense = cd.spread = nullptr;
+            hipError_t he = hipMalloc(&cd.dense, col_bytes);
+            if (he == hipSuccess) he = hipMalloc(&cd.spread, col_bytes);
+            if (he == hipSuccess) he = hipMemset(cd.dense, 0, col_bytes);
+            if (he == hipSuccess) he = hipMemset(cd.spread, 0, col_bytes);
+            if (he != hipSuccess) {                               // out of memory: judge the candidates there are
+                (void)hipFree(cd.dense); (void)hipFree(cd.spread);
+                (void)hipGetLastError();
+                break;
+            }
+        }
+        cands.push_back(cd);
+        c.d_chip_dense = cd.dense;
+        c.d_chip_spread = cd.spread;
+        float best = 0.f;
+        for (int rep = 0; rep < 3 && rc == HSW_OK; rep++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            rc = hsw_gadget_digest_batch(g, n, in.data(), lens.data(), pres.data(), res.data());
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (rc == HSW_OK && (rep == 1 || (rep > 1 && ms < best))) best = ms;
+            const int rr = hsw_gadget_reset(g);
+            if (rc == HSW_OK) rc = rr;
+        }
+        if (rc != HSW_OK) { restore(0); return rc; }
+        cands.back().ms = best;
+    }
+    size_t keep = 0;
+    for (size_t k = 1; k < cands.size(); k++)
+        if (cands[k].ms < cands[keep].ms) keep = k;
+    for (size_t k = 0; k < cands.size() && ms_each; k++) ms_each[k] = cands[k].ms;
+    for (size_t k = cands.size(); k < candidates && ms_each; k++) ms_each[k] = 0.f;
+    if (kept) *kept = (unsigned)keep;
+    restore(keep);
+    hipError_t he = hipMemsetAsync(c.d_chip_dense, 0, col_bytes, stream);       // as a fresh gadget has them
+    if (he == hipSuccess) he = hipMemsetAsync(c.d_chip_spread, 0, col_bytes, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    return he == hipSuccess ? HSW_OK : HSW_ERR_HIP;
 } HSW_NO_UNWIND
 
 int hsw_gadget_download_region(hsw_gadget *g, const hsw_region_host *dst) try {

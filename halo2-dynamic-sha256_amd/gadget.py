@@ -152,6 +152,14 @@ class Sha256DynamicConfig:
             out["lookup"] = lookup[: int(v.lookup_cells)]
         return out
 
+    def place(self, candidates=3):
+        """hsw_gadget_place: try `candidates` allocations of the chip columns, keep the one the gadget's own batch
+        runs fastest on (fresh or reset gadget).  Returns (batch ms of every candidate, index kept)."""
+        ms = (C.c_float * candidates)()
+        kept = C.c_uint()
+        self._ok(self.lib.hsw_gadget_place(self.h, candidates, ms, C.byref(kept)))
+        return [float(x) for x in ms], int(kept.value)
+
     def download_region_distinct(self, threads=8, bufs=None):
         """Distinct-value delivery: only the new witnesses cross PCIe (hsw_gadget_download_region_distinct into
         pinned memory), the image is rebuilt on the host (hsw_gadget_replay_region).  Returns the same dict as

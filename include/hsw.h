@@ -645,6 +645,15 @@ int hsw_gadget_region_tape(hsw_gadget *g, hsw_region_tape *out);
 int hsw_gadget_download_region_distinct(hsw_gadget *g, void *distinct, size_t cap_cells, size_t *n_cells);
 int hsw_gadget_replay_region(hsw_gadget *g, const void *distinct, const hsw_region_host *dst, unsigned threads);
 
+/* Buffer placement.  On MI355X the same HBM-bound batch runs up to 8 % faster or slower depending on which pair of
+ * allocations its gate stream and its chip columns live in, and nothing in user space predicts it.
+ * On a fresh or reset gadget: allocate the chip columns up to `candidates` (1..16) times, time the gadget's own batch
+ * (every digest an empty message, through hsw_gadget_digest_batch) on each and keep the fastest; the others are
+ * freed, the gadget is left reset.  ms_each (candidates floats, may be NULL) receives every candidate's batch time,
+ * *kept (may be NULL) the index kept.  Worth calling once for gadgets of a few hundred blocks or more; a
+ * latency-bound single digest does not care. */
+int hsw_gadget_place(hsw_gadget *g, unsigned candidates, float *ms_each, unsigned *kept);
+
 /* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
  * (cur_hash_idx, num_limb_sum, the gate / lookup stream cursors, the zero cell) takes the value it
  * would have then.  All of them follow from max_variable_byte_sizes alone -- never from the

@@ -1,7 +1,7 @@
 //! Raw bindings of `include/hsw.h` (ABI version 1).  One item per C declaration;
 //! struct layouts are `#[repr(C)]` mirrors.  Not compiled in the build image.
 #![allow(non_camel_case_types)]
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 #[repr(C)] pub struct hsw_engine { _private: [u8; 0] }
 #[repr(C)] pub struct hsw_gadget { _private: [u8; 0] }
@@ -386,6 +386,8 @@ extern "C" {
                                  lookups_already_queued: u64) -> c_int;
     pub fn hsw_gadget_reset(g: *mut hsw_gadget) -> c_int;
     pub fn hsw_gadget_seek(g: *mut hsw_gadget, hash_idx: usize) -> c_int;
+    /// Buffer placement: try `candidates` allocations of the chip columns, keep the one the gadget's own batch runs fastest on.
+    pub fn hsw_gadget_place(g: *mut hsw_gadget, candidates: c_uint, ms_each: *mut f32, kept: *mut c_uint) -> c_int;
     pub fn hsw_verify_frames(e: *mut hsw_engine, descs: *const hsw_frame_desc, n: usize, d_blocks: *const u8,
                              d_pre_states: *const u32, d_next_states: *const u32, d_gate: *const c_void,
                              d_lookup: *const c_void, pack: *const hsw_pack_plan, flags: u32,

@@ -128,6 +128,11 @@ impl Backend {
         // the column image from (0, 0); every synthesis pass re-bases it on where its Context stands (set_origin)
         let mut columns = 0u64;
         check(unsafe { sys::hsw_gadget_set_columns(be.gadget, be.key.4, &mut columns) })?;
+        // where the chip columns sit relative to the gate stream is worth up to 8 % of an HBM-bound batch (DESIGN.md
+        // 5.1): for circuits of a few hundred blocks or more let the gadget try three allocations, once
+        if be.key.0.iter().sum::<usize>() / 64 >= 256 {
+            check(unsafe { sys::hsw_gadget_place(be.gadget, 3, ptr::null_mut(), ptr::null_mut()) })?;
+        }
         let mut tape = unsafe { std::mem::zeroed::<sys::hsw_region_tape>() };
         check(unsafe { sys::hsw_gadget_region_tape(be.gadget, &mut tape) })?;
         be.distinct_cells = tape.distinct_capacity as usize + 1;             // every digest of the circuit

@@ -117,8 +117,14 @@ static void whole_region() {
             CHECK(rc.n_input_bytes == 128 && rc.output_byte_pos[31][0] >= v.origin_column);
         }
     };
+    // placement: three candidate allocations of the chip columns, two freed again (LeakSanitizer watches)
+    float ms_each[3];
+    unsigned kept = 99;
+    CHECK(hsw_gadget_place(g, 3, ms_each, &kept) == HSW_OK && kept < 3);
+    CHECK(hsw_gadget_place(g, 0, nullptr, nullptr) == HSW_ERR_INVALID_ARG && hsw_gadget_place(g, 17, nullptr, nullptr) == HSW_ERR_INVALID_ARG);
     // pass 1: linear stream (the compact staging is sized for it)
     digest_both();
+    CHECK(hsw_gadget_place(g, 2, nullptr, nullptr) == HSW_ERR_INVALID_ARG);           // digests assigned
     deliver();
     // pass 2: the FlexGate image of a Context that stands at (2, 131000) -- a larger geometry than pass 1
     // (the staging was sized once and a later, larger image overflowed it)

@@ -92,3 +92,32 @@ def test_witness_digests_public_entry_and_pinned_pointer_check(hsw, oracle):
     assert eng.lib.hsw_witness_digests(eng.h, C.byref(a)) == N.HSW_OK
     eng.synchronize()
     eng.close()
+
+
+def test_gadget_place_keeps_results_and_one_set_of_buffers(hsw, oracle):
+    """hsw_gadget_place: candidate allocations of the chip columns, the gadget's own batch timed on each, the fastest
+    kept.  Whatever it keeps, the gadget writes the same region afterwards; refused once digests are assigned."""
+    import hashlib
+    N = hsw._native
+    eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
+    sizes, msgs = [128, 64, 192], [b"place", b"", bytes(range(150))]
+    cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=True, whole_digest=True)
+    before = (int(cfg.view().d_chip_dense), int(cfg.view().d_chip_spread))
+    ms, kept = cfg.place(4)
+    assert len(ms) == 4 and all(m > 0 for m in ms) and 0 <= kept < 4
+    v = cfg.view()
+    assert int(v.gate_cells) == 0 and int(v.num_limb_sum) == 0                     # left reset
+    assert (kept == 0) == ((int(v.d_chip_dense), int(v.d_chip_spread)) == before)
+    res = cfg.digest_batch(msgs)
+    assert [r.output_bytes for r in res] == [hashlib.sha256(m).digest() for m in msgs]
+    st = cfg.streams()
+    ref = oracle.digest_cells(msgs, sizes, None, True)
+    assert np.array_equal(st["gate"], ref["gate"]) and np.array_equal(st["lookup"], ref["lookup"])
+    assert np.array_equal(st["dense"], ref["dense"][:, : st["rows"]]) and np.array_equal(st["spread"], ref["spread"][:, : st["rows"]])
+    assert cfg.verify()["violations"] == 0
+    with pytest.raises(hsw.HswError):
+        cfg.place(2)                                                               # digests assigned in this pass
+    cfg.reset()
+    assert cfg.place(1)[1] == 0                                                    # one candidate = what is there
+    cfg.close()
+    eng.close()
