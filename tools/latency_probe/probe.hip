@@ -14,6 +14,7 @@
 
 namespace hsw {
 template hipError_t launch_expand_L<2>(const ExpandParams &, int, hipStream_t);
+template hipError_t launch_expand_m32<2>(const ExpandParams &, hipStream_t);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
