@@ -93,8 +93,8 @@ int main(int argc, char **argv) {
     if (argc > 1) {      /* sweep of the "helpers" option: waves per workgroup of the small-batch kernel */
         for (int mont = 0; mont < 2; mont++)
             for (int blocks = 1; blocks <= 32; blocks = blocks == 1 ? 2 : blocks * 2)
-                for (int h = 1; h <= 4; h++) {
-                    if (h == 3) continue;
+                for (int h = 1; h <= (argc > 2 ? atoi(argv[2]) : 4); h++) {      /* `sweep 6` against a build with more helper waves */
+                    if (h == 3 || h == 5) continue;
                     run(1, 64 * (size_t)blocks, 3, -1, blocks > 16 ? 18 : 17, mont, h);
                 }
         return 0;
