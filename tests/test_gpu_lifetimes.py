@@ -121,3 +121,24 @@ def test_gadget_place_keeps_results_and_one_set_of_buffers(hsw, oracle):
     assert cfg.place(1)[1] == 0                                                    # one candidate = what is there
     cfg.close()
     eng.close()
+
+
+def test_alloc_outputs_placed_changes_where_not_what(hsw, oracle):
+    """WitnessEngine.alloc_outputs_placed: candidate allocations of the chip columns, the launch timed on each, the
+    fastest pair kept -- the same bytes as with any other buffers."""
+    import torch
+    rng = np.random.default_rng(8)
+    n = 40
+    blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    eng = hsw.WitnessEngine(0, 8, 2)
+    out, rep = eng.alloc_outputs_placed(tb, tp, cursor0=6, candidates=3, spacer_bytes=1 << 20)
+    assert rep["candidates"] == 3 and len(rep["kernel_ms_each"]) == 3 and 0 <= rep["kept"] < 3
+    eng.witness_blocks(tb, tp, cursor0=6, out=out)
+    eng.synchronize()
+    ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, pre, cursor0=6)
+    assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+    assert np.array_equal(out["spread"].cpu().numpy().view(np.uint64), ref["spread"])
+    eng.close()
