@@ -928,11 +928,14 @@ def run_rank(args):
     start, count = sh.shard_range(n * world, world, rank)          # contiguous shard of the global batch
     assert count == n
     cursor0 = sh.shard_cursor(0, start, eng.limb_calls)            # rows land where the serial reference would put them
-    # Where the chip columns sit relative to the gate stream decides between 1.64 and 1.77 ms per launch on this
-    # part (profiles/r03_placement_probe.log; nothing in user space predicts it), so -- like a prover that allocates
-    # its witness buffers once -- the launch is timed on a few candidate allocations of the chip columns and the
-    # best pair is kept.  --placement-candidates 1 = take the first allocation as it comes.
-    out, placement = eng.alloc_outputs_placed(blocks, pre, cursor0=cursor0, candidates=args.placement_candidates)
+    # Where the gate stream and the chip columns sit decides between 1.58 and 1.78 ms per launch on this part
+    # (profiles/r03_placement_probe.log; nothing in user space predicts it), so -- like a prover that allocates its
+    # witness buffers once -- the launch is timed on a few candidate allocations (gate stream: hsw_device_alloc
+    # ranges and plain buffers; chip columns: plain buffers and ranges of smaller pieces) and the best combination
+    # is kept.  --placement-candidates 1 = take the first allocation as it comes (plain buffers).
+    one = args.placement_candidates <= 1
+    out, placement = eng.alloc_outputs_placed(blocks, pre, cursor0=cursor0, candidates=max(args.placement_candidates, 1),
+                                              gate_candidates=1 if one else 3, ranged=not one)
     eng.set_timing(True)
 
     def step():
@@ -1071,10 +1074,11 @@ def run_rank(args):
                 "calibrated_fill_GBps": fill_gbs,
                 "calibrated_fill_note": "hsw_fill_calibrate on the same gate buffer: every wave streams its own contiguous 64 KiB "
                                         "chunks, the best pure-write pattern found on this part (tools/fillbench)",
-                "placement": dict(placement, note="the launch timed on this many candidate allocations of the chip columns "
-                                  "(rank 0's), the fastest pair of buffers kept: on MI355X the same launch takes 1.64 or 1.77 ms "
-                                  "depending on where its chip columns sit relative to its gate stream "
-                                  "(profiles/r03_placement_probe.log); kernel_ms_each[0] is what the first allocation gave"),
+                "placement": dict(placement, note="rank 0's: the launch timed on every combination of the candidate gate buffers "
+                                  "(rows of kernel_ms) and candidate chip-column allocations (columns), the fastest kept: on MI355X the "
+                                  "same launch takes between 1.58 and 1.78 ms depending on where its buffers sit "
+                                  "(profiles/r03_placement_probe.log, DESIGN.md 5.1); the 'plain' row, first column, is what torch's "
+                                  "allocator gives as it comes"),
                 "kernel_ms_per_rank": {"min": min(kernel_ms_per_rank), "max": max(kernel_ms_per_rank), "ranks": kernel_ms_per_rank},
                 "frac_per_rank": {"min": alg_bytes * n / (max(kernel_ms_per_rank) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "max": alg_bytes * n / (min(kernel_ms_per_rank) * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -1105,8 +1109,8 @@ def main():
     ap.add_argument("--messages-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="candidate allocations of the chip columns timed before the run (1 = the first one as it comes)")
+    ap.add_argument("--placement-candidates", type=int, default=6,
+                    help="candidate allocations of the chip columns (x 3 candidate gate buffers) timed before the run; 1 = plain buffers as they come")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")

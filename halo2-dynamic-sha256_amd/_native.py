@@ -182,7 +182,7 @@ SYMBOLS = (
     "hsw_shape_query_ex", "hsw_engine_create_ex", "hsw_pack_plan_query", "hsw_gate_tape",
     "hsw_witness_blocks_ex", "hsw_spread_table", "hsw_cell_bytes", "hsw_neg_cells",
     "hsw_frame_query", "hsw_frame_tape", "hsw_witness_frames", "hsw_gadget_create_ex",
-    "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_place", "hsw_gadget_download_region",
+    "hsw_gadget_set_columns", "hsw_gadget_cell_position", "hsw_gadget_reset", "hsw_gadget_seek", "hsw_gadget_place", "hsw_device_alloc", "hsw_device_free", "hsw_gadget_download_region",
     "hsw_block_structure", "hsw_frame_structure", "hsw_verify_blocks",
     "hsw_verify_frames", "hsw_gadget_verify", "hsw_last_launch", "hsw_witness_digests",
     "hsw_gadget_download_region_compact", "hsw_region_widen", "hsw_gadget_result_cells",
@@ -324,6 +324,10 @@ def lib():
         L.hsw_gadget_download_region.argtypes = [vp, C.POINTER(RegionHost)]
         L.hsw_gadget_seek.restype = C.c_int
         L.hsw_gadget_seek.argtypes = [vp, C.c_size_t]
+        L.hsw_device_alloc.restype = C.c_int
+        L.hsw_device_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.hsw_device_free.restype = C.c_int
+        L.hsw_device_free.argtypes = [vp]
         L.hsw_gadget_place.restype = C.c_int
         L.hsw_gadget_place.argtypes = [vp, C.c_uint, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
         L.hsw_gadget_reset.restype = C.c_int

@@ -24,6 +24,20 @@ class _Pinned:
             pass
 
 
+class _DeviceRange:
+    """Owner of one hsw_device_alloc range, exposed to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, lib, ptr, shape, typestr):
+        self.lib, self.ptr = lib, ptr
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(ptr, False), version=2, strides=None)
+
+    def __del__(self):
+        try:
+            self.lib.hsw_device_free(self.ptr)
+        except Exception:
+            pass
+
+
 class WitnessEngine:
     """One hsw_engine bound to (device, stream).
 
@@ -77,56 +91,90 @@ class WitnessEngine:
     def chip_rows(self, cursor0, n_blocks):
         return int(self.lib.hsw_chip_rows(C.byref(self.shape), cursor0, n_blocks))
 
-    def alloc_outputs(self, n_blocks, cursor0=0, flags=0):
+    def device_empty(self, shape, chunk_bytes=0):
+        """An int64 tensor in an hsw_device_alloc range (one virtual range backed by physical allocations of up to
+        chunk_bytes, 0 = 4 GiB): where the witness launch's gate stream ran fastest (tools/vmmprobe)."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        p = C.c_void_p()
+        self._ok(self.lib.hsw_device_alloc(self.device.index or 0, max(n, 1) * 8, chunk_bytes, C.byref(p)))
+        return self.torch.as_tensor(_DeviceRange(self.lib, p.value, shape, "<i8"), device=self.device)
+
+    def alloc_outputs(self, n_blocks, cursor0=0, flags=0, ranged=False):
         """Allocate the three output buffers for n_blocks blocks in HBM (cells are
-        4 x int64, or 1 x int64 with HSW_REPR_COMPACT64)."""
+        4 x int64, or 1 x int64 with HSW_REPR_COMPACT64).  ranged: the gate stream in an hsw_device_alloc range."""
         t = self.torch
         rows = self.chip_rows(cursor0, n_blocks)
         w = 1 if (flags & N.HSW_REPR_COMPACT64) else 4
-        gate = t.empty((n_blocks * self.G, w), dtype=t.int64, device=self.device)
+        gate = None
+        if ranged:
+            try:
+                gate = self.device_empty((n_blocks * self.G, w))
+            except N.HswError:                  # no virtual memory management on this stack: a plain buffer
+                gate = None
+        if gate is None:
+            gate = t.empty((n_blocks * self.G, w), dtype=t.int64, device=self.device)
         dense = t.zeros((self.ncols, max(rows, 1), w), dtype=t.int64, device=self.device)
         spread = t.zeros((self.ncols, max(rows, 1), w), dtype=t.int64, device=self.device)
         nxt = t.empty((n_blocks, 8), dtype=t.int32, device=self.device)
         return dict(gate=gate, dense=dense, spread=spread, next_states=nxt, rows=rows)
 
-    def alloc_outputs_placed(self, blocks, pre_states, cursor0=0, flags=0, candidates=6, spacer_bytes=6 << 30):
-        """alloc_outputs with a measured choice of WHERE the chip columns sit relative to the gate stream.
+    def alloc_outputs_placed(self, blocks, pre_states, cursor0=0, flags=0, candidates=6, spacer_bytes=6 << 30, ranged=True,
+                             gate_candidates=3):
+        """alloc_outputs with a measured choice of WHERE the gate stream and the chip columns live.
 
-        On MI355X the same launch takes 1.64 or 1.77 ms per 4,096 blocks depending on the PAIR of allocations its
+        On MI355X the same launch takes between 1.58 and 1.78 ms per 4,096 blocks depending on the allocations its
         gate stream and its chip columns live in (profiles/r03_placement_probe.log: the pure fill of either buffer
-        and the launch without chip columns do not care; two regions of ONE allocation are always the slow case).
-        Nothing in user space says which pairs are fast, so a caller that allocates its witness buffers once and
-        reuses them -- a prover does -- times the launch itself on a few candidates and keeps the best:
-        `candidates` (dense, spread) allocations, spaced out by throw-away allocations of `spacer_bytes`.
-        Returns (outputs, report)."""
+        and the launch without chip columns do not care; two regions of ONE plain allocation are always a slow
+        case; a gate stream in an hsw_device_alloc range of 4 GiB physical pieces was the fastest in most processes,
+        yet not in all).  Nothing in user space says which combinations are fast, so a caller that allocates its
+        witness buffers once and reuses them -- a prover does -- times the launch itself on a few candidates and
+        keeps the best: `gate_candidates` gate buffers (hsw_device_alloc ranges and plain ones alternating when
+        `ranged`) x `candidates` (dense, spread) pairs (plain ones and ranges of smaller pieces alternating, spaced
+        out by throw-away allocations of `spacer_bytes`).  Returns (outputs, report)."""
         t = self.torch
         n = blocks.numel() // 64
-        out = self.alloc_outputs(n, cursor0, flags)
         timing_was = getattr(self, "_timing", False)
         self.set_timing(True)
+        gates, kinds = [], []
+        for g in range(max(gate_candidates, 1)):
+            try:
+                o = self.alloc_outputs(n, cursor0, flags, ranged=ranged and g % 2 == 0)
+            except (RuntimeError, N.HswError):
+                break
+            gates.append(o)
+            kinds.append("range of 4 GiB pieces" if ranged and g % 2 == 0 else "plain")
+        out = gates[0]
+        pairs, spacers, pair_kinds = [(out["dense"], out["spread"])], [], ["plain"]
+        for k in range(1, max(candidates, 1)):
+            try:
+                spacers.append(t.empty((spacer_bytes,), dtype=t.uint8, device=self.device))
+                if ranged and k % 2 == 1:     # every other candidate in hsw_device_alloc ranges of 32 MiB / 256 MiB / 2 GiB pieces
+                    chunk = (32 << 20) << (3 * ((k // 2) % 3))
+                    pairs.append((self.device_empty(out["dense"].shape, chunk).zero_(), self.device_empty(out["spread"].shape, chunk).zero_()))
+                    pair_kinds.append("ranges of %d MiB pieces" % (chunk >> 20))
+                else:
+                    pairs.append((t.zeros_like(out["dense"]), t.zeros_like(out["spread"])))
+                    pair_kinds.append("plain")
+            except (RuntimeError, N.HswError):          # out of memory: keep what we have
+                break
 
-        def time_pair(dense, spread):
-            o = dict(out, dense=dense, spread=spread)
+        def time_on(gate_out, dense, spread):
+            o = dict(gate_out, dense=dense, spread=spread)
             ms = []
             for _ in range(4):
                 self.witness_blocks(blocks, pre_states, cursor0=cursor0, out=o, flags=flags)
                 ms.append(self.last_kernel_ms())
             return float(min(ms[1:]))
 
-        pairs, spacers, times = [(out["dense"], out["spread"])], [], []
-        times.append(time_pair(*pairs[0]))
-        for _ in range(max(candidates - 1, 0)):
-            try:
-                spacers.append(t.empty((spacer_bytes,), dtype=t.uint8, device=self.device))
-                pairs.append((t.zeros_like(out["dense"]), t.zeros_like(out["spread"])))
-            except RuntimeError:          # out of memory: keep what we have
-                break
-            times.append(time_pair(*pairs[-1]))
-        best = int(min(range(len(times)), key=lambda k: times[k]))
-        out["dense"], out["spread"] = pairs[best]
-        del pairs, spacers
+        table = [[time_on(go, d, s_) for d, s_ in pairs] for go in gates]
+        bg, bp = min(((g, p) for g in range(len(gates)) for p in range(len(pairs))), key=lambda gp: table[gp[0]][gp[1]])
+        out = dict(gates[bg], dense=pairs[bp][0], spread=pairs[bp][1])
+        del pairs, spacers, gates
         self.set_timing(timing_was)
-        return out, dict(candidates=len(times), kernel_ms_each=times, kept=best)
+        return out, dict(gate_candidates=kinds, chip_candidates=pair_kinds, kernel_ms=table, kept=[bg, bp],
+                         candidates=len(kinds) * len(pair_kinds), kernel_ms_each=[x for row in table for x in row])
 
     # ---- the hot path ----------------------------------------------------
     def witness_blocks(self, blocks, pre_states, cursor0=0, out=None, flags=0):

@@ -327,6 +327,16 @@ int hsw_witness_blocks_host(hsw_engine *e, const uint8_t *blocks, const uint32_t
 int hsw_host_alloc(size_t bytes, void **out);
 void hsw_host_free(void *p);
 
+/* Device memory for witness streams: one contiguous virtual range of `bytes` bytes on `device`, backed by separate
+ * physical allocations of up to chunk_bytes each (0 = 4 GiB) through HIP's virtual memory management.  On MI355X the
+ * write rate of an HBM-bound launch depends on where its output buffers sit; a gate stream in such a
+ * range ran 2-4 % faster than in one plain hipMalloc buffer in every process tried, and was much less sensitive to
+ * where the chip columns are (tools/vmmprobe).  Any device pointer works with every entry point of this library;
+ * this is an offer, not a requirement.  hsw_device_free waits for the device, unmaps and releases the range;
+ * HSW_ERR_INVALID_ARG for a pointer that did not come from hsw_device_alloc. */
+int hsw_device_alloc(int device, size_t bytes, size_t chunk_bytes, void **out);
+int hsw_device_free(void *ptr);
+
 /* Duration in milliseconds of the most recent expansion kernel launched by
  * hsw_witness_blocks on this engine, measured with HIP events recorded on the
  * engine's stream around that launch.  Synchronizes on the stop event. */

@@ -423,6 +423,9 @@ extern "C" {
     pub fn hsw_download(e: *mut hsw_engine, host_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn hsw_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn hsw_host_free(p: *mut c_void);
+    /// Device memory for witness streams: one virtual range backed by physical allocations of up to `chunk_bytes` (0 = 4 GiB).
+    pub fn hsw_device_alloc(device: c_int, bytes: usize, chunk_bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn hsw_device_free(ptr: *mut c_void) -> c_int;
     pub fn hsw_fill_calibrate(e: *mut hsw_engine, d_buf: *mut c_void, bytes: usize, ms: *mut f32) -> c_int;
     pub fn hsw_last_kernel_ms(e: *mut hsw_engine, ms: *mut f32) -> c_int;
     pub fn hsw_set_timing(e: *mut hsw_engine, enabled: c_int) -> c_int;

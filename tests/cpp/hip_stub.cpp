@@ -124,6 +124,29 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     *grid = g_grid; *block = g_block; *shmem = g_shmem; *stream = g_stream;
     return hipSuccess;
 }
+// virtual memory management (hsw_devmem.cpp): a reserved range is heap memory, physical handles are counted
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipMemGetAllocationGranularity(size_t *g, const hipMemAllocationProp *, hipMemAllocationGranularity_flags) { *g = 4096; return hipSuccess; }
+hipError_t hipMemAddressReserve(void **p, size_t bytes, size_t, void *, unsigned long long) { return hipMalloc(p, bytes); }
+hipError_t hipMemAddressFree(void *p, size_t bytes) {
+    auto it = g_device.find(p);
+    if (it == g_device.end() || it->second != bytes) die("hipMemAddressFree of a range that was not reserved like this");
+    return hipFree(p);
+}
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t bytes, const hipMemAllocationProp *, unsigned long long) {
+    void *q = std::malloc(16);
+    g_device[q] = bytes;                                   // a live physical allocation: leaks show up like any other
+    *h = reinterpret_cast<hipMemGenericAllocationHandle_t>(q);
+    return hipSuccess;
+}
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { return hipFree(reinterpret_cast<void *>(h)); }
+hipError_t hipMemMap(void *p, size_t bytes, size_t, hipMemGenericAllocationHandle_t, unsigned long long) {
+    if (!inside(g_device, p) || !inside(g_device, static_cast<char *>(p) + bytes - 1)) die("hipMemMap outside a reserved range");
+    return hipSuccess;
+}
+hipError_t hipMemUnmap(void *p, size_t) { if (!inside(g_device, p)) die("hipMemUnmap outside a reserved range"); return hipSuccess; }
+hipError_t hipMemSetAccess(void *p, size_t, const hipMemAccessDesc *, size_t) { if (!inside(g_device, p)) die("hipMemSetAccess outside a reserved range"); return hipSuccess; }
+
 hipError_t hipLaunchKernel(const void *, dim3 grid, dim3 block, void **, size_t, hipStream_t) {
     if (grid.x == 0 || block.x == 0 || block.x * block.y * block.z > 1024) return hipErrorInvalidConfiguration;
     g_launches++;

@@ -68,6 +68,21 @@ static void block_batches() {
     }
 }
 
+// hsw_device_alloc: ranges of several physical pieces, freed in any order, a foreign pointer refused
+static void device_ranges() {
+    void *a = nullptr, *b = nullptr;
+    CHECK(hsw_device_alloc(0, 10 * 4096 + 1, 3 * 4096, &a) == HSW_OK && a);        // 11 pages in pieces of 3: 4 physical allocations
+    CHECK(hsw_device_alloc(0, 1, 0, &b) == HSW_OK && b);
+    void *c = nullptr;
+    CHECK(hsw_device_alloc(0, 0, 0, &c) == HSW_ERR_INVALID_ARG);
+    CHECK(hsw_device_alloc(3, 4096, 0, &c) == HSW_ERR_NO_DEVICE && c == nullptr);
+    std::memset(a, 0x5a, 10 * 4096 + 1);                                            // (heap memory under the stub)
+    int on_stack = 0;
+    CHECK(hsw_device_free(&on_stack) == HSW_ERR_INVALID_ARG);
+    CHECK(hsw_device_free(a) == HSW_OK && hsw_device_free(a) == HSW_ERR_INVALID_ARG);
+    CHECK(hsw_device_free(b) == HSW_OK && hsw_device_free(nullptr) == HSW_OK);
+}
+
 // the whole-region gadget through two synthesis passes with a geometry change in between
 static void whole_region() {
     hsw_engine *e = nullptr;
@@ -218,6 +233,7 @@ static void pinned_pointer_validation() {
 
 int main() {
     block_batches();
+    device_ranges();
     whole_region();
     pinned_pointer_validation();
     // everything the library allocated is gone with its engines and gadgets

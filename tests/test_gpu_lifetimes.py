@@ -133,12 +133,41 @@ def test_alloc_outputs_placed_changes_where_not_what(hsw, oracle):
     pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
     tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
     eng = hsw.WitnessEngine(0, 8, 2)
-    out, rep = eng.alloc_outputs_placed(tb, tp, cursor0=6, candidates=3, spacer_bytes=1 << 20)
-    assert rep["candidates"] == 3 and len(rep["kernel_ms_each"]) == 3 and 0 <= rep["kept"] < 3
+    out, rep = eng.alloc_outputs_placed(tb, tp, cursor0=6, candidates=3, spacer_bytes=1 << 20, gate_candidates=2)
+    assert rep["gate_candidates"] == ["range of 4 GiB pieces", "plain"] and len(rep["chip_candidates"]) == 3
+    assert len(rep["kernel_ms"]) == 2 and all(len(row) == 3 for row in rep["kernel_ms"])
+    assert 0 <= rep["kept"][0] < 2 and 0 <= rep["kept"][1] < 3
     eng.witness_blocks(tb, tp, cursor0=6, out=out)
     eng.synchronize()
     ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, pre, cursor0=6)
     assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
     assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
     assert np.array_equal(out["spread"].cpu().numpy().view(np.uint64), ref["spread"])
+    eng.close()
+
+
+def test_device_ranges_hold_witness_streams(hsw, oracle):
+    """hsw_device_alloc: one virtual range backed by several physical allocations -- a witness launch writes through
+    the piece boundaries like anywhere else; freed once, a second free is refused."""
+    import torch
+    N = hsw._native
+    rng = np.random.default_rng(12)
+    n = 24                                                   # 24 x 66,308 cells x 32 B = 50.9 MB: pieces of 4 MiB -> 13 allocations
+    blocks = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    pre = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    tb, tp = torch.from_numpy(blocks).cuda(), torch.from_numpy(pre.view(np.int32)).cuda()
+    eng = hsw.WitnessEngine(0, 8, 2)
+    out = eng.alloc_outputs(n)
+    out["gate"] = eng.device_empty(out["gate"].shape, chunk_bytes=4 << 20)
+    out["dense"] = eng.device_empty(out["dense"].shape, chunk_bytes=2 << 20).zero_()
+    eng.witness_blocks(tb, tp, out=out)
+    eng.synchronize()
+    ref = oracle.Oracle(8, 2, check=False).witness_blocks(blocks, pre)
+    assert np.array_equal(out["gate"].cpu().numpy().view(np.uint64), ref["gate"])
+    assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
+    del out
+    p = C.c_void_p()
+    assert eng.lib.hsw_device_alloc(0, 1 << 20, 0, C.byref(p)) == 0 and p.value
+    assert eng.lib.hsw_device_free(p) == 0 and eng.lib.hsw_device_free(p) == N.HSW_ERR_INVALID_ARG
+    assert eng.lib.hsw_device_alloc(0, 0, 0, C.byref(p)) == N.HSW_ERR_INVALID_ARG
     eng.close()

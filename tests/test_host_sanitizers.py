@@ -41,7 +41,7 @@ def host_objects(tmp_path_factory):
     if not all(os.path.exists(k) for k in kernels):
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j8"])
     out = str(tmp_path_factory.mktemp("san"))
-    objs = [_compile(hipcc, os.path.join(CSRC, f), out) for f in ("hsw_api.cpp", "hsw_api_region.cpp", "hsw_gadget.cpp", "hsw_replay.cpp")]
+    objs = [_compile(hipcc, os.path.join(CSRC, f), out) for f in ("hsw_api.cpp", "hsw_api_region.cpp", "hsw_gadget.cpp", "hsw_replay.cpp", "hsw_devmem.cpp")]
     return hipcc, out, objs, kernels
 
 
