@@ -32,7 +32,18 @@ rng = np.random.default_rng(0xC3)
 blocks = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
 pre = torch.from_numpy(np.tile(np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32).view(np.int32), (n, 1))).cuda()
 G = 69348 if MODE else 66308
-gate = torch.empty((n * G, 4), dtype=torch.int64, device="cuda")  # sized for 32-byte cells; compact runs use a quarter
+if os.environ.get("HSW_AB_RANGED") == "1":       # the gate stream in an hsw_device_alloc range (4 GiB physical pieces)
+    class _Ptr:
+        def __init__(self, p, cells): self.p, self.cells = p, cells
+        def data_ptr(self): return self.p
+        def numel(self): return self.cells * 4
+    _p = C.c_void_p()
+    _L = variants[0][1]
+    _L.hsw_device_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    assert _L.hsw_device_alloc(0, n * G * 32, 0, C.byref(_p)) == 0
+    gate = _Ptr(_p.value, n * G)
+else:
+    gate = torch.empty((n * G, 4), dtype=torch.int64, device="cuda")  # sized for 32-byte cells; compact runs use a quarter
 dense = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
 spread = torch.zeros((2, 2060 * n, 4), dtype=torch.int64, device="cuda")
 nxt = torch.empty((n, 8), dtype=torch.int32, device="cuda")
