@@ -953,42 +953,6 @@ int hsw_gadget_place(hsw_gadget *g, unsigned candidates, float *ms_each, unsigne
     for (size_t k = cands.size(); k < candidates && ms_each; k++) ms_each[k] = 0.f;
     if (kept) *kept = (unsigned)keep;
     restore(keep);
-    if (candidates >= 2) {
-        // ... and the gate region in its other backing (an hsw_device_alloc range <-> one plain buffer): kept if the
-        // batch runs faster there.  (A fresh or reset gadget: nothing in the region needs to survive.)
-        const size_t gate_bytes = (c.max_rows ? (size_t)(c.columns * c.max_rows)
-                                              : c.whole ? (size_t)c.gate_capacity : c.capacity_blocks * (size_t)s.gate_cells_per_block) * HSW_CELL_BYTES;
-        void *alt = nullptr;
-        bool alt_is_range = false;
-        hipError_t ha;
-        if (c.gate_is_range) ha = hipMalloc(&alt, gate_bytes ? gate_bytes : 1);
-        else { ha = hsw_device_alloc(device, gate_bytes ? gate_bytes : 1, 0, &alt) == HSW_OK ? hipSuccess : hipErrorOutOfMemory; alt_is_range = ha == hipSuccess; }
-        if (ha == hipSuccess) ha = hipMemset(alt, 0, gate_bytes);
-        if (ha == hipSuccess) {
-            void *old = c.d_gate;
-            c.d_gate = alt;
-            float best = 0.f;
-            for (int rep = 0; rep < 3 && rc == HSW_OK; rep++) {
-                const auto t0 = std::chrono::steady_clock::now();
-                rc = hsw_gadget_digest_batch(g, n, in.data(), lens.data(), pres.data(), res.data());
-                const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                if (rc == HSW_OK && (rep == 1 || (rep > 1 && ms < best))) best = ms;
-                const int rr = hsw_gadget_reset(g);
-                if (rc == HSW_OK) rc = rr;
-            }
-            if (rc == HSW_OK && best < cands[keep].ms) {
-                hsw::Context::gate_free(old, c.gate_is_range);
-                c.gate_is_range = alt_is_range;
-            } else {
-                c.d_gate = old;
-                hsw::Context::gate_free(alt, alt_is_range);
-            }
-            if (rc != HSW_OK) return rc;
-        } else {
-            hsw::Context::gate_free(alt, alt_is_range);
-            (void)hipGetLastError();
-        }
-    }
     hipError_t he = hipMemsetAsync(c.d_chip_dense, 0, col_bytes, stream);       // as a fresh gadget has them
     if (he == hipSuccess) he = hipMemsetAsync(c.d_chip_spread, 0, col_bytes, stream);
     if (he == hipSuccess) he = hipStreamSynchronize(stream);

@@ -664,10 +664,8 @@ int hsw_gadget_replay_region(hsw_gadget *g, const void *distinct, const hsw_regi
  * On a fresh or reset gadget: allocate the chip columns up to `candidates` (1..16) times, time the gadget's own batch
  * (every digest an empty message, through hsw_gadget_digest_batch) on each and keep the fastest; the others are
  * freed, the gadget is left reset.  ms_each (candidates floats, may be NULL) receives every candidate's batch time,
- * *kept (may be NULL) the index kept.  With two or more candidates the gate region is then tried in its other
- * backing too (one plain buffer <-> an hsw_device_alloc range, cf. HSW_GADGET_RANGED) and moved there if the batch
- * runs faster.  Worth calling once for gadgets of a few hundred blocks or more; a latency-bound single digest does
- * not care.  Device pointers of an earlier hsw_gadget_streams view are stale afterwards. */
+ * *kept (may be NULL) the index kept.  Worth calling once for gadgets of a few hundred blocks or more; a
+ * latency-bound single digest does not care. */
 int hsw_gadget_place(hsw_gadget *g, unsigned candidates, float *ms_each, unsigned *kept);
 
 /* Position the context as if digests #0 .. #hash_idx-1 had already been assigned: every cursor
