@@ -608,11 +608,10 @@ def extra_config0(hsw, local_rank, with_cpu):
             lens_ = (C.c_size_t * K)(*([56] * K))
             pres_ = (C.c_size_t * K)(*([0] * K))
             resv = (hsw._native.HashResult * K)()
-            cfgk = hsw.Sha256DynamicConfig(eng_i, [1024] * K, True, whole_digest=True, independent=True, ranged=K >= 64)
+            cfgk = hsw.Sha256DynamicConfig(eng_i, [1024] * K, True, whole_digest=True, independent=True)
             if form == "montgomery":
                 cfgk.set_repr(hsw._native.HSW_REPR_MONTGOMERY)
-            # placement (see roofline.placement): the region in an hsw_device_alloc range (HSW_GADGET_RANGED), and
-            # hsw_gadget_place tries three allocations of the chip columns for
+            # placement (see roofline.placement): hsw_gadget_place tries three allocations of the chip columns for
             # the HBM-bound batches and keeps the one the gadget's own batch runs fastest on
             placed_ms = cfgk.place(3)[0] if K >= 64 else None
             tk = []

@@ -33,7 +33,6 @@ HSW_MAX_BREAKS = 16
 HSW_CELL_BYTES = 32
 HSW_GADGET_WHOLE_DIGEST = 1
 HSW_GADGET_INDEPENDENT = 2
-HSW_GADGET_RANGED = 4
 NO_CELL = (1 << 64) - 1
 
 

@@ -211,21 +211,8 @@ std::vector<std::pair<uint64_t, uint64_t>> Sha256DynamicConfig::load() const {
     return rows;
 }
 
-// The gate region: a plain buffer, or (HSW_GADGET_RANGED) one virtual range backed by 4 GiB physical allocations --
-// where an HBM-bound launch wrote fastest in most processes; a refused range is a plain buffer.
-int Context::gate_alloc(void **p, size_t bytes, int device, bool *is_range) const {
-    *is_range = false;
-    if (ranged && hsw_device_alloc(device, bytes ? bytes : 1, 0, p) == HSW_OK) { *is_range = true; return (int)hipSuccess; }
-    return (int)hipMalloc(p, bytes);
-}
-void Context::gate_free(void *p, bool is_range) {
-    if (!p) return;
-    if (is_range) (void)hsw_device_free(p);
-    else (void)hipFree(p);
-}
-
 Context::~Context() {
-    gate_free(d_gate, gate_is_range); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
+    (void)hipFree(d_gate); (void)hipFree(d_chip_dense); (void)hipFree(d_chip_spread);
     (void)hipFree(d_next_states); (void)hipFree(d_blocks); (void)hipFree(d_pre_states);
     (void)hipFree(d_init_states); (void)hipFree(d_offsets); (void)hipFree(d_lookup);
     if (hp_blocks) (void)hipHostFree(hp_blocks);
@@ -241,7 +228,7 @@ void Context::free_compact_staging() {
     wide_cap = 0;
 }
 
-int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest, bool independent, bool ranged) const {
+int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool whole_digest, bool independent) const {
     if (!engine || !out) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
@@ -257,7 +244,6 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
     if (!c) return HSW_ERR_NOMEM;
     c->engine = engine;
     c->shape = s;
-    c->ranged = ranged;
     size_t total = 0;
     for (size_t b : max_variable_byte_sizes) total += b / 64;
     c->capacity_blocks = total;
@@ -287,7 +273,7 @@ int Sha256DynamicConfig::new_context(hsw_engine *engine, Context **out, bool who
         c->lookup_capacity = c->own_lookup_capacity = lookups;
         gate_cells = (size_t)cells;
     }
-    hipError_t he = (hipError_t)c->gate_alloc(&c->d_gate, gate_cells * HSW_CELL_BYTES, device, &c->gate_is_range);
+    hipError_t he = hipMalloc(&c->d_gate, gate_cells * HSW_CELL_BYTES);
     // touch the stream buffers once: the first write into fresh device memory is several times slower
     // (measured: 16-block digests 266 us instead of 54 us while a context's buffer was still untouched)
     if (he == hipSuccess) he = hipMemset(c->d_gate, 0, gate_cells * HSW_CELL_BYTES);
@@ -376,13 +362,11 @@ int Context::set_columns(const std::vector<size_t> &sizes, bool rc_inputs, uint6
     if (!ds2.ok) return HSW_ERR_NO_DEVICE;
     // (outstanding work on the old image: the callers -- hsw_gadget_set_columns / _set_origin -- run on a drained engine)
     void *img = nullptr;
-    bool img_is_range = false;
-    hipError_t he = (hipError_t)gate_alloc(&img, (size_t)(cols * rows) * HSW_CELL_BYTES, device, &img_is_range);
+    hipError_t he = hipMalloc(&img, (size_t)(cols * rows) * HSW_CELL_BYTES);
     if (he == hipSuccess) he = hipMemset(img, 0, (size_t)(cols * rows) * HSW_CELL_BYTES);   // unassigned advice cells are 0
-    if (he != hipSuccess) { gate_free(img, img_is_range); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
-    gate_free(d_gate, gate_is_range);
+    if (he != hipSuccess) { if (img) (void)hipFree(img); return he == hipErrorOutOfMemory ? HSW_ERR_NOMEM : HSW_ERR_HIP; }
+    (void)hipFree(d_gate);
     d_gate = img;
-    gate_is_range = img_is_range;
     free_compact_staging();                               // sized for the old geometry
     max_rows = rows;
     columns = cols;
@@ -723,7 +707,7 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                          int is_input_range_check, uint32_t flags, hsw_gadget **out) try {
     if (!e || !out || (!max_variable_byte_sizes && n_hashes)) return HSW_ERR_INVALID_ARG;
-    if (flags & ~(HSW_GADGET_WHOLE_DIGEST | HSW_GADGET_INDEPENDENT | HSW_GADGET_RANGED)) return HSW_ERR_INVALID_ARG;
+    if (flags & ~(HSW_GADGET_WHOLE_DIGEST | HSW_GADGET_INDEPENDENT)) return HSW_ERR_INVALID_ARG;
     if ((flags & HSW_GADGET_INDEPENDENT) && !(flags & HSW_GADGET_WHOLE_DIGEST)) return HSW_ERR_INVALID_ARG;
     *out = nullptr;
     hsw_shape s;
@@ -734,8 +718,7 @@ int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, s
     std::vector<size_t> sizes(max_variable_byte_sizes, max_variable_byte_sizes + n_hashes);
     rc = hsw::Sha256DynamicConfig::configure(sizes, s.num_bits_lookup, s.num_advice_columns,
                                              is_input_range_check != 0, &g->cfg);
-    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0, (flags & HSW_GADGET_INDEPENDENT) != 0,
-                                             (flags & HSW_GADGET_RANGED) != 0);
+    if (rc == HSW_OK) rc = g->cfg.new_context(e, &g->ctx, (flags & HSW_GADGET_WHOLE_DIGEST) != 0, (flags & HSW_GADGET_INDEPENDENT) != 0);
     if (rc != HSW_OK) { delete g; return rc; }
     *out = g;
     return HSW_OK;

@@ -74,7 +74,7 @@ class Sha256DynamicConfig {
 
     // lib.rs:351-360: a context sized for every hash this config will assign.
     // whole_digest: also lay out digest()'s own cells (HSW_GADGET_WHOLE_DIGEST)
-    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false, bool independent = false, bool ranged = false) const;
+    int new_context(hsw_engine *engine, Context **out, bool whole_digest = false, bool independent = false) const;
 
     // lib.rs:71-349.  precomputed_input_len = 0 is the reference's None.
     int digest(Context &ctx, const uint8_t *input, size_t input_len, size_t precomputed_input_len,
@@ -122,10 +122,6 @@ class Context {
     // digest, back to back) and d_lookup the lookup-advice stream next to it
     bool whole = false;
     bool independent = false;        // HSW_GADGET_INDEPENDENT: every digest is a Context of its own (K proofs in flight)
-    bool ranged = false;             // HSW_GADGET_RANGED: d_gate lives in an hsw_device_alloc range (4 GiB physical pieces)
-    bool gate_is_range = false;      // what d_gate currently IS (a failed range falls back to a plain buffer)
-    int gate_alloc(void **p, size_t bytes, int device, bool *is_range) const;     // 0, or the hipError_t of the plain allocation
-    static void gate_free(void *p, bool is_range);
     bool zero_loaded = false;        // Context.zero_cell (first load_zero: compression.rs:34 of the first block)
     uint64_t gate_cursor = 0, gate_capacity = 0;       // cells
     void *d_lookup = nullptr;

@@ -35,12 +35,10 @@ class AssignedHashResult:
 class Sha256DynamicConfig:
     """configure (lib.rs:49-69) + new_context (lib.rs:351-360) in one object."""
 
-    def __init__(self, engine, max_variable_byte_sizes, is_input_range_check=True, whole_digest=False, independent=False,
-                 ranged=False):
+    def __init__(self, engine, max_variable_byte_sizes, is_input_range_check=True, whole_digest=False, independent=False):
         """whole_digest: also emit the cells digest() itself allocates (lib.rs:122-178, 294-341;
         SURVEY 8 f4, assumption A4) -- needs an engine in HSW_MODE_HALO2_INTERNALS.
-        independent: every digest is a synthesis of its own (HSW_GADGET_INDEPENDENT: K proofs in one launch);
-        ranged: the gate region in an hsw_device_alloc range (HSW_GADGET_RANGED)."""
+        independent: every digest is a synthesis of its own (HSW_GADGET_INDEPENDENT: K proofs in one launch)."""
         self.engine = engine
         self.whole_digest = bool(whole_digest)
         self.lib = engine.lib
@@ -50,8 +48,7 @@ class Sha256DynamicConfig:
         rc = self.lib.hsw_gadget_create_ex(engine.h, arr, len(self.max_variable_byte_sizes),
                                            1 if is_input_range_check else 0,
                                            (N.HSW_GADGET_WHOLE_DIGEST if whole_digest else 0) |
-                                           (N.HSW_GADGET_INDEPENDENT if independent else 0) |
-                                           (N.HSW_GADGET_RANGED if ranged else 0), C.byref(h))
+                                           (N.HSW_GADGET_INDEPENDENT if independent else 0), C.byref(h))
         if rc != N.HSW_OK:
             raise N.HswError(rc, self.lib.hsw_last_error(engine.h).decode())
         self.h = h

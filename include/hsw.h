@@ -542,10 +542,6 @@ int hsw_gadget_create(hsw_engine *e, const size_t *max_variable_byte_sizes, size
  * (needs n_blocks * limb_calls_per_block to be a multiple of num_advice_columns: HSW_ERR_UNSUPPORTED otherwise).
  * Linear streams only: hsw_gadget_set_columns / hsw_gadget_set_origin return HSW_ERR_UNSUPPORTED. */
 #define HSW_GADGET_INDEPENDENT  2u
-/* The gadget's gate region lives in an hsw_device_alloc range (one virtual range backed by 4 GiB physical
- * allocations) instead of one plain buffer: where HBM-bound batches wrote fastest in most processes.
- * Worth setting for gadgets of a few hundred blocks or more; a refused range silently becomes a plain buffer. */
-#define HSW_GADGET_RANGED       4u
 int hsw_gadget_create_ex(hsw_engine *e, const size_t *max_variable_byte_sizes, size_t n_hashes,
                          int is_input_range_check, uint32_t flags, hsw_gadget **out);
 void hsw_gadget_destroy(hsw_gadget *g);

@@ -29,7 +29,6 @@ pub const HSW_MAX_BREAKS: usize = 16;
 pub const HSW_CELL_BYTES: usize = 32;
 pub const HSW_GADGET_WHOLE_DIGEST: u32 = 1;
 pub const HSW_GADGET_INDEPENDENT: u32 = 2;
-pub const HSW_GADGET_RANGED: u32 = 4;
 
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]

@@ -89,9 +89,7 @@ static void whole_region() {
     CHECK(hsw_engine_create_ex(0, nullptr, 8, 2, HSW_MODE_HALO2_INTERNALS, &e) == HSW_OK);
     const size_t sizes[2] = {128, 128};
     hsw_gadget *g = nullptr;
-    CHECK(hsw_gadget_create_ex(e, sizes, 2, 1, HSW_GADGET_WHOLE_DIGEST | 8u, &g) == HSW_ERR_INVALID_ARG);      // unknown flag
-    // (its gate region in an hsw_device_alloc range: allocated, re-allocated by every set_columns below, freed at the end)
-    CHECK(hsw_gadget_create_ex(e, sizes, 2, 1, HSW_GADGET_WHOLE_DIGEST | HSW_GADGET_RANGED, &g) == HSW_OK);
+    CHECK(hsw_gadget_create_ex(e, sizes, 2, 1, HSW_GADGET_WHOLE_DIGEST, &g) == HSW_OK);
     hsw_hash_result r[2];
     auto digest_both = [&] {
         CHECK(hsw_gadget_digest(g, (const uint8_t *)"abc", 3, 0, &r[0]) == HSW_OK);

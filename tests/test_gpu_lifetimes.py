@@ -171,31 +171,3 @@ def test_device_ranges_hold_witness_streams(hsw, oracle):
     assert eng.lib.hsw_device_free(p) == 0 and eng.lib.hsw_device_free(p) == N.HSW_ERR_INVALID_ARG
     assert eng.lib.hsw_device_alloc(0, 0, 0, C.byref(p)) == N.HSW_ERR_INVALID_ARG
     eng.close()
-
-
-@pytest.mark.parametrize("columns", [False, True], ids=["linear", "columns"])
-def test_ranged_gadget_writes_the_same_region(hsw, columns):
-    """HSW_GADGET_RANGED: the gate region in an hsw_device_alloc range (also after set_columns re-allocates it) --
-    the same bytes as a plain gadget, through the deliveries too."""
-    N = hsw._native
-    eng = hsw.WitnessEngine(0, 8, 2, mode=N.HSW_MODE_HALO2_INTERNALS)
-    sizes, msgs = [256, 128, 1024], [b"ranged", bytes(range(100)), bytes([7] * 900)]
-    got = []
-    for ranged in (False, True):
-        cfg = hsw.Sha256DynamicConfig(eng, sizes, is_input_range_check=True, whole_digest=True, ranged=ranged)
-        cfg.set_repr(N.HSW_REPR_MONTGOMERY)
-        if columns:
-            cfg.set_origin(1, 77, False, 5)
-            cfg.set_columns(300007)
-        cfg.digest_batch(msgs)
-        assert cfg.verify()["violations"] == 0
-        st = cfg.streams()
-        host = cfg.download_region(pinned=False)
-        dist = cfg.download_region_distinct(threads=2)
-        for k in ("gate", "dense", "spread"):
-            assert np.array_equal(host[k], st[k]) and np.array_equal(dist[k], st[k]), k
-        got.append(st)
-        cfg.close()
-    for k in ("gate", "lookup", "dense", "spread"):
-        assert np.array_equal(got[0][k], got[1][k]), k
-    eng.close()
