@@ -934,8 +934,11 @@ def run_rank(args):
     # ranges and plain buffers; chip columns: plain buffers and ranges of smaller pieces) and the best combination
     # is kept.  --placement-candidates 1 = take the first allocation as it comes (plain buffers).
     one = args.placement_candidates <= 1
-    out, placement = eng.alloc_outputs_placed(blocks, pre, cursor0=cursor0, candidates=max(args.placement_candidates, 1),
-                                              gate_candidates=1 if one else 3, ranged=not one)
+    try:
+        out, placement = eng.alloc_outputs_placed(blocks, pre, cursor0=cursor0, candidates=max(args.placement_candidates, 1),
+                                                  gate_candidates=1 if one else 3, ranged=not one)
+    except Exception as ex:                  # whatever goes wrong while choosing: plain buffers as they come
+        out, placement = eng.alloc_outputs(n, cursor0), {"error": repr(ex)}
     eng.set_timing(True)
 
     def step():
